@@ -1,0 +1,124 @@
+"""ctypes binding of libaa_mi355.so (C ABI: include/aa_mi355.h).
+
+The library is the only compute backend of this package: if it cannot be loaded the import of any
+op fails loudly (RuntimeError) -- there is no eager/PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+AA_F16, AA_BF16, AA_F32 = 0, 1, 2
+AA_ACT_NONE, AA_ACT_SILU = 0, 1
+
+
+class AaConvGemm(C.Structure):
+    _fields_ = [
+        ("a0", C.c_void_p), ("a1", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("rowvec", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32),
+        ("n_img", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("h_virt", C.c_int32),
+        ("w_virt", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
+        ("n_out", C.c_int32), ("n_pad", C.c_int32), ("k_pad", C.c_int32),
+        ("rowvec_div", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
+        ("act", C.c_int32), ("geglu", C.c_int32), ("bias_per_row", C.c_int32),
+        ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("out_scale", C.c_float),
+    ]
+
+
+class AaGroupNorm(C.Structure):
+    _fields_ = [
+        ("x0", C.c_void_p), ("x1", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("y", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32), ("n_groups_img", C.c_int32), ("tokens_per_group", C.c_int32),
+        ("num_groups", C.c_int32), ("silu", C.c_int32), ("dtype", C.c_int32), ("eps", C.c_float),
+    ]
+
+
+class AaAttnOperand(C.Structure):
+    _fields_ = [
+        ("ptr", C.c_void_p), ("outer_stride", C.c_int64), ("inner_stride", C.c_int64), ("pos_stride", C.c_int64),
+        ("ld", C.c_int32), ("col0", C.c_int32), ("outer_div", C.c_int32), ("_pad", C.c_int32),
+    ]
+
+
+class AaAttention(C.Structure):
+    _fields_ = [
+        ("q", AaAttnOperand), ("k", AaAttnOperand), ("v", AaAttnOperand), ("o", AaAttnOperand),
+        ("n_outer", C.c_int32), ("n_inner", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
+        ("q_len", C.c_int32), ("kv_len", C.c_int32), ("dtype", C.c_int32), ("scale", C.c_float),
+    ]
+
+
+class AaDpmStep(C.Structure):
+    _fields_ = [
+        ("eps_uncond", C.c_void_p), ("eps_text", C.c_void_p), ("latents", C.c_void_p), ("x0_prev", C.c_void_p),
+        ("latents_lp", C.c_void_p), ("n", C.c_int64),
+        ("guidance", C.c_float), ("sigma_s", C.c_float), ("alpha_s", C.c_float),
+        ("c_x", C.c_float), ("c_d0", C.c_float), ("c_d1", C.c_float), ("dtype", C.c_int32),
+    ]
+
+
+SYMBOLS = ("aa_version", "aa_last_error", "aa_conv_gemm", "aa_groupnorm_workspace", "aa_groupnorm",
+           "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step")
+
+DEFAULT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaa_mi355.so")
+
+
+def bind(path: str) -> C.CDLL:
+    """dlopen `path` and attach the prototypes of include/aa_mi355.h."""
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -m animate_anything_amd.build` "
+                           "(hipcc --offload-arch=gfx950); this package has no fallback backend")
+    lib = C.CDLL(path)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise RuntimeError(f"{path} does not export {s}")
+    lib.aa_version.restype = C.c_int
+    lib.aa_last_error.restype = C.c_char_p
+    lib.aa_conv_gemm.argtypes = [C.POINTER(AaConvGemm), C.c_void_p]
+    lib.aa_groupnorm_workspace.argtypes = [C.POINTER(AaGroupNorm)]
+    lib.aa_groupnorm_workspace.restype = C.c_size_t
+    lib.aa_groupnorm.argtypes = [C.POINTER(AaGroupNorm), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.aa_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                 C.c_float, C.c_int32, C.c_void_p]
+    lib.aa_attention.argtypes = [C.POINTER(AaAttention), C.c_void_p]
+    lib.aa_softmax_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+    lib.aa_cfg_dpm_step.argtypes = [C.POINTER(AaDpmStep), C.c_void_p]
+    for s in SYMBOLS[2:]:
+        if s != "aa_groupnorm_workspace":
+            getattr(lib, s).restype = C.c_int
+    return lib
+
+
+_lib = None
+_host_pointers_ok = False     # only the emulator build (tests/emu) accepts host memory
+
+
+def get() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = bind(DEFAULT_PATH)
+    return _lib
+
+
+def host_pointers_ok() -> bool:
+    return _host_pointers_ok
+
+
+class use_library:
+    """Test hook: route ops through another build of the same C ABI (the CPU SIMT emulator of
+    tests/emu).  Never used by the product path."""
+
+    def __init__(self, lib, host_pointers=False):
+        self.lib, self.host = lib, host_pointers
+
+    def __enter__(self):
+        global _lib, _host_pointers_ok
+        self.prev = (_lib, _host_pointers_ok)
+        _lib, _host_pointers_ok = self.lib, self.host
+        return self.lib
+
+    def __exit__(self, *a):
+        global _lib, _host_pointers_ok
+        _lib, _host_pointers_ok = self.prev

@@ -1,0 +1,35 @@
+"""Build libaa_mi355.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libaa_mi355.so")
+
+
+def _deps():
+    deps = [os.path.join(ROOT, "include", "aa_mi355.h")]
+    for d, _, fs in os.walk(CSRC):
+        deps += [os.path.join(d, f) for f in fs if f.endswith((".h", ".hip"))]
+    return deps
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/aa_api.hip -> libaa_mi355.so (skipped when up to date). Returns the path."""
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _deps()):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffast-math",
+           "-I", os.path.join(CSRC, "kernels", "device"), "-I", os.path.join(CSRC, "kernels"), "-I", CSRC,
+           "-I", os.path.join(ROOT, "include"),
+           os.path.join(CSRC, "aa_api.hip"), "-o", LIB]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(force=True, verbose="-v" in sys.argv))

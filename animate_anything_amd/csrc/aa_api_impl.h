@@ -1,0 +1,174 @@
+// C-ABI entry points of libaa_mi355.so (declared in include/aa_mi355.h): argument validation, tile
+// configuration choice and kernel launches.  The translation unit that includes this file defines
+//   AA_LAUNCH(kernel, grid, block, lds_bytes, stream, args...)
+// (csrc/aa_api.hip: a HIP launch on the caller's stream; tests/emu/aa_api_emu.cpp: the CPU SIMT emulator)
+// and AA_POST_LAUNCH() returning a failure string or nullptr.
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+#include "aa_mi355.h"
+#include "kernels/conv_gemm.h"
+#include "kernels/norm.h"
+#include "kernels/attention.h"
+
+namespace aa {
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int finish(const char* what) {
+    const char* e = AA_POST_LAUNCH();
+    if (e) return fail(AA_E_HIP, "%s: %s", what, e);
+    return AA_OK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+static int conv_gemm_t(const AaConvGemm& d, void* stream) {
+    const int64_t M64 = (int64_t)d.n_img * d.h_out * d.w_out;
+    const int M = (int)M64;
+    // BN = 128 unless the packed width only fills 64-column tiles (N = 320, 960, conv_out ...)
+    const bool bn128 = (d.n_pad % 128 == 0);
+    const int bn = bn128 ? 128 : 64;
+    if (d.geglu && !bn128) return fail(AA_E_SHAPE, "conv_gemm: GEGLU needs n_pad %% 128 == 0 (got %d)", d.n_pad);
+    const int tiles_m = (M + CG_BM - 1) / CG_BM;
+    const int tiles_n = d.n_pad / bn;
+    const dim3 grid(tiles_m * tiles_n), block(CG_THREADS);
+    if (bn128) AA_LAUNCH((conv_gemm_kernel<T, 128>), grid, block, cg_lds_bytes(128), stream, d, M, tiles_n);
+    else       AA_LAUNCH((conv_gemm_kernel<T, 64>), grid, block, cg_lds_bytes(64), stream, d, M, tiles_n);
+    return finish("conv_gemm");
+}
+
+template <typename T>
+static int groupnorm_t(const AaGroupNorm& d, float* ws, int chunks, int apply_chunks, void* stream) {
+    const int C = d.c0 + d.c1;
+    AA_LAUNCH((groupnorm_stats_kernel<T>), dim3(chunks, d.n_groups_img), dim3(GN_THREADS), (size_t)C * 8, stream, d, ws, chunks);
+    const size_t lds = ((size_t)2 * C + 2 * (GN_THREADS + d.num_groups)) * 4;
+    AA_LAUNCH((groupnorm_apply_kernel<T>), dim3(apply_chunks, d.n_groups_img), dim3(GN_THREADS), lds, stream, d, (const float*)ws, chunks, apply_chunks);
+    return finish("groupnorm");
+}
+
+static int gn_chunks(const AaGroupNorm& d) {
+    // aim for >= ~1024 workgroups, at least 64 tokens each
+    int want = (1024 + d.n_groups_img - 1) / d.n_groups_img;
+    int cap = (d.tokens_per_group + 63) / 64;
+    int c = want < cap ? want : cap;
+    return c < 1 ? 1 : c;
+}
+
+template <typename T>
+static int attention_t(const AaAttention& d, void* stream) {
+    const int nseq = d.n_outer * d.n_inner;
+    if (d.q_len > 64) {
+        const dim3 grid((d.q_len + 127) / 128, d.heads, nseq);
+        AA_LAUNCH((attention_kernel<T, 4>), grid, dim3(256), attn_lds_bytes(), stream, d);
+    } else {
+        const dim3 grid((d.q_len + 31) / 32, d.heads, nseq);
+        AA_LAUNCH((attention_kernel<T, 1>), grid, dim3(64), attn_lds_bytes(), stream, d);
+    }
+    return finish("attention");
+}
+
+}  // namespace aa
+
+extern "C" {
+
+int aa_version(void) { return AA_VERSION; }
+const char* aa_last_error(void) { return aa::g_err; }
+
+int aa_conv_gemm(const AaConvGemm* d, void* stream) {
+    using namespace aa;
+    if (!d) return fail(AA_E_SHAPE, "conv_gemm: null descriptor");
+    const int ctot = d->c0 + d->c1;
+    if (d->c0 <= 0 || d->c0 % 8 || d->c1 % 8 || (d->c1 > 0 && !d->a1))
+        return fail(AA_E_SHAPE, "conv_gemm: channels must be multiples of 8 (c0=%d c1=%d)", d->c0, d->c1);
+    if (d->n_pad % 64 || d->k_pad % CG_BK || d->k_pad < d->kh * d->kw * ctot || d->n_out > d->n_pad)
+        return fail(AA_E_SHAPE, "conv_gemm: bad packed extents n_pad=%d k_pad=%d (K=%d, n_out=%d)", d->n_pad, d->k_pad, d->kh * d->kw * ctot, d->n_out);
+    if (d->n_img <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->rowvec_div <= 0)
+        return fail(AA_E_SHAPE, "conv_gemm: bad geometry");
+    if ((int64_t)d->n_img * d->h_out * d->w_out >= (int64_t)1 << 31) return fail(AA_E_SHAPE, "conv_gemm: M overflows int32");
+    if (!aligned16(d->a0) || !aligned16(d->a1) || !aligned16(d->w)) return fail(AA_E_ALIGN, "conv_gemm: operands must be 16-byte aligned");
+    if (d->out_dtype != AA_F32 && d->out_dtype != d->dtype) return fail(AA_E_DTYPE, "conv_gemm: out_dtype must be dtype or f32");
+    if (d->dtype == AA_F16) return conv_gemm_t<f16_t>(*d, stream);
+    if (d->dtype == AA_BF16) return conv_gemm_t<bf16_t>(*d, stream);
+    return fail(AA_E_DTYPE, "conv_gemm: unsupported dtype %d", d->dtype);
+}
+
+size_t aa_groupnorm_workspace(const AaGroupNorm* d) {
+    return (size_t)d->n_groups_img * aa::gn_chunks(*d) * d->num_groups * 2 * sizeof(float);
+}
+
+int aa_groupnorm(const AaGroupNorm* d, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace aa;
+    if (!d) return fail(AA_E_SHAPE, "groupnorm: null descriptor");
+    const int C = d->c0 + d->c1;
+    if (d->c0 <= 0 || d->c0 % 8 || d->c1 % 8 || d->num_groups <= 0 || C % d->num_groups || d->num_groups > GN_THREADS)
+        return fail(AA_E_SHAPE, "groupnorm: bad channels c0=%d c1=%d groups=%d", d->c0, d->c1, d->num_groups);
+    if (d->n_groups_img <= 0 || d->tokens_per_group <= 0) return fail(AA_E_SHAPE, "groupnorm: bad token geometry");
+    if (!aligned16(d->x0) || !aligned16(d->x1) || !aligned16(d->y)) return fail(AA_E_ALIGN, "groupnorm: operands must be 16-byte aligned");
+    const size_t need = aa_groupnorm_workspace(d);
+    if (!workspace || workspace_bytes < need) return fail(AA_E_WORKSPACE, "groupnorm: workspace %zu < %zu bytes", workspace_bytes, need);
+    const int chunks = gn_chunks(*d);
+    if (d->dtype == AA_F16) return groupnorm_t<f16_t>(*d, (float*)workspace, chunks, chunks, stream);
+    if (d->dtype == AA_BF16) return groupnorm_t<bf16_t>(*d, (float*)workspace, chunks, chunks, stream);
+    return fail(AA_E_DTYPE, "groupnorm: unsupported dtype %d", d->dtype);
+}
+
+int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t channels,
+                 float eps, int32_t dtype, void* stream) {
+    using namespace aa;
+    if (rows <= 0 || channels <= 0 || channels % 8 || channels > 2048) return fail(AA_E_SHAPE, "layernorm: rows=%lld channels=%d", (long long)rows, channels);
+    if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta)) return fail(AA_E_ALIGN, "layernorm: operands must be 16-byte aligned");
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == AA_F16) AA_LAUNCH((layernorm_kernel<f16_t>), grid, block, 0, stream, (const f16_t*)x, (const f16_t*)gamma, (const f16_t*)beta, (f16_t*)y, rows, channels, eps);
+    else if (dtype == AA_BF16) AA_LAUNCH((layernorm_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, rows, channels, eps);
+    else return fail(AA_E_DTYPE, "layernorm: unsupported dtype %d", dtype);
+    return finish("layernorm");
+}
+
+int aa_attention(const AaAttention* d, void* stream) {
+    using namespace aa;
+    if (!d) return fail(AA_E_SHAPE, "attention: null descriptor");
+    if (d->head_dim != 64) return fail(AA_E_SHAPE, "attention: head_dim must be 64 (got %d)", d->head_dim);
+    if (d->q_len <= 0 || d->kv_len <= 0 || d->heads <= 0 || d->n_outer <= 0 || d->n_inner <= 0) return fail(AA_E_SHAPE, "attention: bad lengths");
+    const AaAttnOperand* ops[4] = {&d->q, &d->k, &d->v, &d->o};
+    for (const AaAttnOperand* x : ops) {
+        if (!aligned16(x->ptr) || x->ld % 8 || x->col0 % 8) return fail(AA_E_ALIGN, "attention: operand rows must be 16-byte aligned");
+        if (x->outer_div <= 0) return fail(AA_E_SHAPE, "attention: outer_div must be >= 1");
+    }
+    if (d->dtype == AA_F16) return attention_t<f16_t>(*d, stream);
+    if (d->dtype == AA_BF16) return attention_t<bf16_t>(*d, stream);
+    return fail(AA_E_DTYPE, "attention: unsupported dtype %d", d->dtype);
+}
+
+int aa_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int32_t dtype, void* stream) {
+    using namespace aa;
+    if (rows <= 0 || cols <= 0) return fail(AA_E_SHAPE, "softmax_rows: bad shape");
+    const dim3 grid((unsigned)rows), block(256);
+    if (dtype == AA_F16) AA_LAUNCH((softmax_rows_kernel<f16_t>), grid, block, 64, stream, x, (f16_t*)y, cols);
+    else if (dtype == AA_BF16) AA_LAUNCH((softmax_rows_kernel<bf16_t>), grid, block, 64, stream, x, (bf16_t*)y, cols);
+    else return fail(AA_E_DTYPE, "softmax_rows: unsupported dtype %d", dtype);
+    return finish("softmax_rows");
+}
+
+int aa_cfg_dpm_step(const AaDpmStep* d, void* stream) {
+    using namespace aa;
+    if (!d || d->n <= 0) return fail(AA_E_SHAPE, "cfg_dpm_step: bad size");
+    int64_t blocks = (d->n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (d->dtype == AA_F16) AA_LAUNCH((cfg_dpm_step_kernel<f16_t>), grid, block, 0, stream, *d);
+    else if (d->dtype == AA_BF16) AA_LAUNCH((cfg_dpm_step_kernel<bf16_t>), grid, block, 0, stream, *d);
+    else return fail(AA_E_DTYPE, "cfg_dpm_step: unsupported dtype %d", d->dtype);
+    return finish("cfg_dpm_step");
+}
+
+}  // extern "C"

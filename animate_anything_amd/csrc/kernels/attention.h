@@ -1,0 +1,172 @@
+// Flash-style attention for gfx950, head_dim 64 (see include/aa_mi355.h: aa_attention).
+//
+// One wavefront owns 32 query rows of one (sequence, head); NW wavefronts of a workgroup share each
+// 64-key K/V tile through LDS.  The score tile is computed TRANSPOSED, S^T = K Q^T, so that in the
+// 32x32 MFMA result layout (col = lane&31) every lane owns one query row: the online-softmax max and
+// sum are register-local (one xor-32 shuffle joins the two half-waves), and the exponentiated
+// registers are, unchanged, the B operand of O^T = V^T P^T.  V is written to LDS transposed with its
+// keys permuted inside each 16-key chunk (quads 1 and 2 swapped) so the matching A operand is a
+// single ds_read_b128.  Softmax runs in base 2 on scores pre-multiplied by scale*log2(e).
+#pragma once
+#include "dev.h"
+#include "aa_mi355.h"
+
+namespace aa {
+
+constexpr int AT_KT = 64;       // keys per tile
+constexpr int AT_LDS = 72;      // padded LDS row (elements)
+
+__host__ __device__ inline int attn_lds_bytes() { return 2 * AT_KT * AT_LDS * 2; }
+
+template <typename T>
+__device__ __forceinline__ const T* attn_row(const AaAttnOperand& x, int o, int i, int pos, int head) {
+    const int64_t row = (int64_t)(o / x.outer_div) * x.outer_stride + (int64_t)i * x.inner_stride + (int64_t)pos * x.pos_stride;
+    return reinterpret_cast<const T*>(x.ptr) + row * x.ld + x.col0 + head * 64;
+}
+
+template <typename T, int NW>
+__global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p) {
+    constexpr int THREADS = 64 * NW;
+    constexpr int SLOTS = (AT_KT * 8) / THREADS;     // 16-byte K (and V) slots staged per thread
+    T* sK = reinterpret_cast<T*>(dyn_smem());        // [64 keys][72]
+    T* sVt = sK + AT_KT * AT_LDS;                    // [64 d][72]  (keys permuted)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, ql = lane & 31;
+    const int head = blockIdx.y;
+    const int seq = blockIdx.z;
+    const int o = seq / p.n_inner, i = seq - o * p.n_inner;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const bool wave_active = q0 < p.q_len;
+    const float sl2e = p.scale * 1.4426950408889634f;
+
+    // Q fragment: B operand of S^T (col = query, k = d)
+    u32x4 qf[4];
+    {
+        const int q = q0 + ql;
+        const bool ok = q < p.q_len;
+        const T* src = attn_row<T>(p.q, o, i, ok ? q : 0, head) + 8 * h;
+#pragma unroll
+        for (int dk = 0; dk < 4; ++dk) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(src + 16 * dk);
+            qf[dk] = v;
+        }
+    }
+
+    u32x4 rk[SLOTS], rv[SLOTS];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int sl = tid + s * THREADS;
+            const int key = kt * AT_KT + (sl >> 3), dseg = sl & 7;
+            const bool ok = key < p.kv_len;
+            u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+            if (ok) {
+                a = *reinterpret_cast<const u32x4*>(attn_row<T>(p.k, o, i, key, head) + dseg * 8);
+                b = *reinterpret_cast<const u32x4*>(attn_row<T>(p.v, o, i, key, head) + dseg * 8);
+            }
+            rk[s] = a; rv[s] = b;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int sl = tid + s * THREADS;
+            const int key = sl >> 3, dseg = sl & 7;
+            *reinterpret_cast<u32x4*>(sK + key * AT_LDS + dseg * 8) = rk[s];
+            const int quad = (key >> 2) & 3;
+            const int pos = (key & ~15) | ((((quad & 1) << 1) | (quad >> 1)) << 2) | (key & 3);
+            Pack8<T> v; v.raw = rv[s];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sVt[(dseg * 8 + e) * AT_LDS + pos] = v.e[e];
+        }
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.0f; oacc[1][e] = 0.0f; }
+    float m_run = -1.0e30f, l_run = 0.0f;
+
+    const int ntiles = (p.kv_len + AT_KT - 1) / AT_KT;
+    fetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        stash();
+        __syncthreads();
+        if (kt + 1 < ntiles) fetch(kt + 1);
+        if (wave_active) {
+            f32x16 sacc[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.0f;
+#pragma unroll
+                for (int dk = 0; dk < 4; ++dk) {
+                    const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + (32 * kb + ql) * AT_LDS + 16 * dk + 8 * h);
+                    sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], sacc[kb]);
+                }
+            }
+            // scale, mask, running max
+            float mloc = -1.0e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * AT_KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float s = key < p.kv_len ? sacc[kb][e] * sl2e : -1.0e30f;
+                    sacc[kb][e] = s;
+                    mloc = fmaxf(mloc, s);
+                }
+            mloc = fmaxf(mloc, wave_shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = exp2f(m_run - m_new);
+            m_run = m_new;
+            float psum = 0.0f;
+            u32x4 pf[4];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    Pack8<T> pk;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float pe = exp2f(sacc[kb][8 * c + e] - m_new);
+                        psum += pe;
+                        pk.e[e] = (T)pe;
+                    }
+                    pf[2 * kb + c] = pk.raw;
+                }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const u32x4 vf = *reinterpret_cast<const u32x4*>(sVt + (32 * db + ql) * AT_LDS + 16 * ch + 8 * h);
+                    oacc[db] = mfma_32x32x16(T(), vf, pf[ch], oacc[db]);
+                }
+        }
+        __syncthreads();
+    }
+
+    if (wave_active) {
+        const float l_tot = l_run + wave_shfl_xor(l_run, 32);
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + ql;
+        if (q < p.q_len) {
+            T* dst = const_cast<T*>(attn_row<T>(p.o, o, i, q, head));
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    union { u32x2 raw; T e[4]; } pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk.e[e] = (T)(oacc[db][4 * g + e] * inv);
+                    *reinterpret_cast<u32x2*>(dst + 32 * db + 8 * g + 4 * h) = pk.raw;
+                }
+        }
+    }
+}
+
+}  // namespace aa

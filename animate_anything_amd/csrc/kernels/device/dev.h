@@ -1,0 +1,24 @@
+// gfx950 device primitives used by every kernel: dynamic LDS base, 32x32x16 MFMA wrappers
+// (f16 / bf16 in, f32 accumulate), wave64 cross-lane exchange.  tests/emu/dev.h supplies
+// host-side stand-ins with the same names so kernel bodies can be exercised on the CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../types.h"
+
+__device__ __forceinline__ char* dyn_smem() {
+    extern __shared__ __attribute__((aligned(16))) char aa_lds_[];
+    return aa_lds_;
+}
+
+// D = A(32x16) * B(16x32) + C on one wavefront.  Lane l supplies row (l&31) of A and column
+// (l&31) of B, eight consecutive k each (half-wave l>>5 picks which eight); D comes back as
+// col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for register r (cdna_hip_programming.md section 3).
+__device__ __forceinline__ f32x16 mfma_32x32x16(f16_t, u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, src, 64); }

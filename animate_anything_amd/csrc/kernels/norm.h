@@ -1,0 +1,237 @@
+// HBM-bound normalisation / elementwise kernels for gfx950 (see include/aa_mi355.h):
+// GroupNorm(+SiLU) over channels-last tokens (2-D and clip-wide 3-D statistics, optional two-source
+// channel concat), LayerNorm, row softmax, fused CFG + DPM-Solver++ update.
+// All global traffic is 16 B per lane (8 half-precision channels), statistics in fp32, cross-lane
+// sums by wave64 xor-shuffles, cross-wave sums through LDS.
+#pragma once
+#include "dev.h"
+#include "aa_mi355.h"
+
+namespace aa {
+
+constexpr int GN_THREADS = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += wave_shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, wave_shfl_xor(v, m));
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ u32x4 load8(const T* x0, const T* x1, int c0, int c1, int64_t token, int c) {
+    const T* src = (c < c0) ? x0 + token * c0 + c : x1 + token * c1 + (c - c0);
+    return *reinterpret_cast<const u32x4*>(src);
+}
+
+// ---- GroupNorm pass 1: per (image group, chunk) partial sums of x and x^2 for every channel group.
+// grid = (chunks, n_groups_img).  partial layout: [img_group][chunk][group][2] fp32.
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS) groupnorm_stats_kernel(const AaGroupNorm p, float* partial, int chunks) {
+    float* s_sum = reinterpret_cast<float*>(dyn_smem());      // [C]
+    const int C = p.c0 + p.c1;
+    float* s_sq = s_sum + C;
+    const int tid = threadIdx.x;
+    const int S = C >> 3;                                       // 16-byte slots per token
+    const int ig = blockIdx.y, chunk = blockIdx.x;
+    const int per = (p.tokens_per_group + chunks - 1) / chunks;
+    const int t_begin = chunk * per;
+    const int t_end = min(p.tokens_per_group, t_begin + per);
+    const int64_t base = (int64_t)ig * p.tokens_per_group;
+    const T* x0 = reinterpret_cast<const T*>(p.x0);
+    const T* x1 = reinterpret_cast<const T*>(p.x1);
+
+    for (int c = tid; c < C; c += GN_THREADS) { s_sum[c] = 0.0f; s_sq[c] = 0.0f; }
+    __syncthreads();
+
+    const int rows_per_pass = S <= GN_THREADS ? GN_THREADS / S : 1;
+    for (int s0 = 0; s0 < S; s0 += GN_THREADS) {
+        const int lin = tid;
+        const int slot = s0 + (S <= GN_THREADS ? lin % S : lin);
+        const int roff = S <= GN_THREADS ? lin / S : 0;
+        const bool active = slot < S && roff < rows_per_pass;
+        float a[8], b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = 0.0f; b[e] = 0.0f; }
+        if (active) {
+            for (int t = t_begin + roff; t < t_end; t += rows_per_pass) {
+                Pack8<T> v; v.raw = load8<T>(x0, x1, p.c0, p.c1, base + t, slot * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v.e[e]; a[e] += f; b[e] += f * f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { atomicAdd(&s_sum[slot * 8 + e], a[e]); atomicAdd(&s_sq[slot * 8 + e], b[e]); }
+        }
+    }
+    __syncthreads();
+    if (tid < p.num_groups) {
+        const int cg = C / p.num_groups;
+        float a = 0.0f, b = 0.0f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += s_sum[c]; b += s_sq[c]; }
+        float* dst = partial + (((int64_t)ig * chunks + chunk) * p.num_groups + tid) * 2;
+        dst[0] = a; dst[1] = b;
+    }
+}
+
+// ---- GroupNorm pass 2: finish the statistics (every block redoes the tiny reduction of the partials
+// of its image group), fold them with gamma/beta into per-channel scale/shift in LDS, normalise.
+// grid = (apply_chunks, n_groups_img).
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS) groupnorm_apply_kernel(const AaGroupNorm p, const float* partial, int chunks, int apply_chunks) {
+    const int C = p.c0 + p.c1;
+    float* s_scale = reinterpret_cast<float*>(dyn_smem());     // [C]
+    float* s_shift = s_scale + C;                               // [C]
+    float* s_red = s_shift + C;                                 // [8][num_groups][2] then [num_groups][2]
+    const int tid = threadIdx.x;
+    const int ig = blockIdx.y;
+    const int G = p.num_groups;
+
+    {   // reduce partial[ig][*][g][*]: thread -> (group g, chunk lane j of GN_THREADS/G)
+        const int lanes = GN_THREADS / G;
+        const int g = tid % G, j = tid / G;
+        float a = 0.0f, b = 0.0f;
+        if (j < lanes)
+            for (int ch = j; ch < chunks; ch += lanes) {
+                const float* src = partial + (((int64_t)ig * chunks + ch) * G + g) * 2;
+                a += src[0]; b += src[1];
+            }
+        if (j < lanes) { s_red[(j * G + g) * 2] = a; s_red[(j * G + g) * 2 + 1] = b; }
+        __syncthreads();
+        if (tid < G) {
+            float sa = 0.0f, sb = 0.0f;
+            for (int jj = 0; jj < lanes; ++jj) { sa += s_red[(jj * G + tid) * 2]; sb += s_red[(jj * G + tid) * 2 + 1]; }
+            const float cnt = (float)p.tokens_per_group * (float)(C / G);
+            const float mean = sa / cnt;
+            const float var = fmaxf(sb / cnt - mean * mean, 0.0f);
+            s_red[(lanes * G + tid) * 2] = mean;
+            s_red[(lanes * G + tid) * 2 + 1] = rsqrtf(var + p.eps);
+        }
+        __syncthreads();
+        const T* gamma = reinterpret_cast<const T*>(p.gamma);
+        const T* beta = reinterpret_cast<const T*>(p.beta);
+        const int cg = C / G;
+        for (int c = tid; c < C; c += GN_THREADS) {
+            const int gg = c / cg;
+            const float mean = s_red[(lanes * G + gg) * 2], rstd = s_red[(lanes * G + gg) * 2 + 1];
+            const float sc = rstd * (float)gamma[c];
+            s_scale[c] = sc;
+            s_shift[c] = (float)beta[c] - mean * sc;
+        }
+        __syncthreads();
+    }
+
+    const int S = C >> 3;
+    const int per = (p.tokens_per_group + apply_chunks - 1) / apply_chunks;
+    const int t_begin = blockIdx.x * per;
+    const int t_end = min(p.tokens_per_group, t_begin + per);
+    const int64_t base = (int64_t)ig * p.tokens_per_group;
+    const T* x0 = reinterpret_cast<const T*>(p.x0);
+    const T* x1 = reinterpret_cast<const T*>(p.x1);
+    T* y = reinterpret_cast<T*>(p.y);
+    const int64_t total = (int64_t)(t_end - t_begin) * S;
+    for (int64_t i = tid; i < total; i += GN_THREADS) {
+        const int t = t_begin + (int)(i / S);
+        const int slot = (int)(i % S);
+        Pack8<T> v; v.raw = load8<T>(x0, x1, p.c0, p.c1, base + t, slot * 8);
+        Pack8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = (float)v.e[e] * s_scale[slot * 8 + e] + s_shift[slot * 8 + e];
+            if (p.silu) f = f / (1.0f + __expf(-f));
+            o.e[e] = (T)f;
+        }
+        *reinterpret_cast<u32x4*>(y + (base + t) * C + slot * 8) = o.raw;
+    }
+}
+
+// ---- LayerNorm: one wavefront per row, the row lives in registers (C <= 2048), two-pass variance.
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm_kernel(const T* x, const T* gamma, const T* beta, T* y,
+                                                       int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int S = C >> 3;
+    Pack8<T> v[4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int slot = lane + 64 * j;
+        if (slot < S) {
+            v[j].raw = *reinterpret_cast<const u32x4*>(x + row * C + slot * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[j].e[e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int slot = lane + 64 * j;
+        if (slot < S) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)v[j].e[e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int slot = lane + 64 * j;
+        if (slot < S) {
+            Pack8<T> g, b, o;
+            g.raw = *reinterpret_cast<const u32x4*>(gamma + slot * 8);
+            b.raw = *reinterpret_cast<const u32x4*>(beta + slot * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = (T)(((float)v[j].e[e] - mean) * rstd * (float)g.e[e] + (float)b.e[e]);
+            *reinterpret_cast<u32x4*>(y + row * C + slot * 8) = o.raw;
+        }
+    }
+}
+
+// ---- row softmax of fp32 scores (VAE single-head attention), one workgroup per row.
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* x, T* y, int cols) {
+    float* s_red = reinterpret_cast<float*>(dyn_smem());   // [8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = x + (int64_t)blockIdx.x * cols;
+    T* yr = y + (int64_t)blockIdx.x * cols;
+    float mx = -3.0e38f;
+    for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, xr[c]);
+    mx = wave_max(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sum = 0.0f;
+    for (int c = tid; c < cols; c += 256) sum += __expf(xr[c] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+    for (int c = tid; c < cols; c += 256) yr[c] = (T)(__expf(xr[c] - mx) * inv);
+}
+
+// ---- fused classifier-free guidance + DPM-Solver++(2M) update (elementwise).
+template <typename T>
+__global__ void __launch_bounds__(256) cfg_dpm_step_kernel(const AaDpmStep p) {
+    const T* eu = reinterpret_cast<const T*>(p.eps_uncond);
+    const T* et = reinterpret_cast<const T*>(p.eps_text);
+    float* x = reinterpret_cast<float*>(p.latents);
+    float* x0p = reinterpret_cast<float*>(p.x0_prev);
+    T* lp = reinterpret_cast<T*>(p.latents_lp);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * 256) {
+        const float u = (float)eu[i];
+        const float eps = u + p.guidance * ((float)et[i] - u);
+        const float xi = x[i];
+        const float x0 = (xi - p.sigma_s * eps) / p.alpha_s;
+        const float nx = p.c_x * xi - p.c_d0 * x0 - p.c_d1 * (x0 - x0p[i]);
+        x[i] = nx;
+        x0p[i] = x0;
+        lp[i] = (T)nx;
+    }
+}
+
+}  // namespace aa

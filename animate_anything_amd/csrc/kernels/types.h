@@ -1,0 +1,21 @@
+// Shared plain types for the gfx950 kernels (no HIP runtime dependency: this header is also
+// read by the host-side SIMT emulator used in tests/emu).
+#pragma once
+#include <stdint.h>
+
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte global/LDS transaction
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// 8 half-precision values viewed either as a raw 16-byte word or as elements.
+template <typename T>
+union Pack8 {
+    u32x4 raw;
+    T e[8];
+};

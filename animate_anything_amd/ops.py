@@ -1,0 +1,263 @@
+"""Torch-tensor front end of the C ABI (include/aa_mi355.h).
+
+Tensors only carry device memory here: every function checks its operands, fills the C descriptor
+and enqueues the HIP kernels on torch's current stream.  Activations are channels-last token
+matrices `[tokens, C]` (see DESIGN.md "Data layout").  There is no fallback: operands that are not
+on the GPU raise, as does a missing library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (AA_ACT_NONE, AA_ACT_SILU, AA_BF16, AA_F16, AA_F32, AaAttention, AaAttnOperand,
+                   AaConvGemm, AaDpmStep, AaGroupNorm)
+
+_DT = {torch.float16: AA_F16, torch.bfloat16: AA_BF16, torch.float32: AA_F32}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _check(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda and not _lib.host_pointers_ok():
+            raise RuntimeError("animate_anything_amd ops run on the GPU only (tensor is on %s)" % t.device)
+        if not t.is_contiguous():
+            raise RuntimeError("animate_anything_amd ops need contiguous tensors")
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else None
+
+
+def _run(fn, *args):
+    rc = fn(*args)
+    if rc != 0:
+        raise RuntimeError("libaa_mi355: " + _lib.get().aa_last_error().decode())
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------- weights
+@dataclass
+class PackedWeight:
+    """Weights laid out for aa_conv_gemm: [n_pad, k_pad], k ordered (tap, channel)."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    n_out: int
+    kh: int
+    kw: int
+    cin: int          # channels per tap as stored (after padding to a multiple of 8)
+    geglu: bool = False
+
+    @property
+    def n_pad(self):
+        return self.w.shape[0]
+
+    @property
+    def k_pad(self):
+        return self.w.shape[1]
+
+
+def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu: bool = False) -> PackedWeight:
+    """Pack an nn.Linear [n,k], nn.Conv2d [n,c,kh,kw] or nn.Conv3d [n,c,kt,1,1] weight.
+
+    GEGLU (diffusers `GEGLU.proj`, rows [0,d) = value, [d,2d) = gate) is re-ordered into alternating
+    blocks of 32 value rows / 32 gate rows so that both halves of a pair land in one wave's tile."""
+    w = weight.detach()
+    if w.dim() == 2:
+        n, kh, kw, cin = w.shape[0], 1, 1, w.shape[1]
+        w4 = w.reshape(n, 1, 1, cin)
+    elif w.dim() == 4:
+        n, cin, kh, kw = w.shape
+        w4 = w.permute(0, 2, 3, 1)
+    elif w.dim() == 5:
+        n, cin, kh, kw = w.shape[0], w.shape[1], w.shape[2], 1
+        assert w.shape[3] == 1 and w.shape[4] == 1
+        w4 = w.reshape(n, cin, kh).permute(0, 2, 1).reshape(n, kh, 1, cin)
+    else:
+        raise ValueError("unsupported weight rank %d" % w.dim())
+    cpad = _round_up(cin, 8)
+    if cpad != cin:
+        w4 = torch.nn.functional.pad(w4, (0, cpad - cin))
+    k = kh * kw * cpad
+    w2 = w4.reshape(n, k)
+    b = None if bias is None else bias.detach()
+    if geglu:
+        d = n // 2
+        assert d % 32 == 0, "GEGLU inner width must be a multiple of 32"
+        val = torch.arange(d, device=w.device).reshape(d // 32, 1, 32)
+        src = torch.cat([val, val + d], dim=1).reshape(-1)
+        w2 = w2[src]
+        b = None if b is None else b[src]
+    n_pad, k_pad = _round_up(n, 64), _round_up(k, 64)
+    out = torch.zeros(n_pad, k_pad, dtype=w.dtype, device=w.device)
+    out[:n, :k] = w2
+    if b is not None and geglu and n_pad != n:
+        b = torch.nn.functional.pad(b, (0, n_pad - n))
+    return PackedWeight(out.contiguous(), None if b is None else b.contiguous(), n, kh, kw, cpad, geglu)
+
+
+# ------------------------------------------------------------------------------------- contraction
+@dataclass
+class Geom:
+    """Output grid and source mapping of one aa_conv_gemm call (all in pixels / tokens)."""
+    n_img: int
+    h_in: int
+    w_in: int
+    h_out: int
+    w_out: int
+    stride: int = 1
+    pad_h: int = 0
+    pad_w: int = 0
+    h_virt: int = 0
+    w_virt: int = 0
+
+    @property
+    def rows(self):
+        return self.n_img * self.h_out * self.w_out
+
+
+def linear_geom(rows: int) -> Geom:
+    return Geom(1, 1, rows, 1, rows)
+
+
+def conv3x3_geom(n, h, w, stride=1, pad=1, up_to=None) -> Geom:
+    """3x3 conv over [n,h,w]; `up_to`=(H,W) inserts a nearest resize in front (Upsample2D);
+    stride 2 / pad 1 is the UNet Downsample2D, stride 2 / pad 0 with a one-pixel bottom/right halo
+    the VAE one (F.pad (0,1,0,1))."""
+    hv, wv = (h, w) if up_to is None else up_to
+    if stride == 1:
+        ho, wo = hv, wv
+    elif pad == 1:
+        ho, wo = (hv + 2 - 3) // stride + 1, (wv + 2 - 3) // stride + 1
+    else:
+        ho, wo = (hv + 1 - 3) // stride + 1, (wv + 1 - 3) // stride + 1
+    return Geom(n, h, w, ho, wo, stride, pad, pad, hv, wv)
+
+
+def tconv_geom(clips, frames, hw) -> Geom:
+    """Conv3d (3,1,1), padding (1,0,0): a 3x1 conv over a [clips, frames, hw] grid."""
+    return Geom(clips, frames, hw, frames, hw, 1, 1, 0)
+
+
+def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Tensor] = None,
+              rowvec: Optional[torch.Tensor] = None, rowvec_div: int = 1,
+              residual: Optional[torch.Tensor] = None, act: int = AA_ACT_NONE, out_dtype=None,
+              out_scale: float = 1.0, bias_per_row: bool = False, out: Optional[torch.Tensor] = None,
+              bias: Optional[torch.Tensor] = "packed") -> torch.Tensor:
+    lib = _lib.get()
+    b = pw.bias if isinstance(bias, str) else bias
+    _check(x0, x1, pw.w, b, rowvec, residual, out)
+    c0 = x0.shape[-1]
+    c1 = 0 if x1 is None else x1.shape[-1]
+    if c0 + c1 != pw.cin:
+        raise RuntimeError(f"conv_gemm: activation has {c0}+{c1} channels, weight expects {pw.cin}")
+    n_cols = pw.n_out // 2 if pw.geglu else pw.n_out
+    odt = x0.dtype if out_dtype is None else out_dtype
+    if out is None:
+        out = torch.empty(g.rows, n_cols, dtype=odt, device=x0.device)
+    d = AaConvGemm()
+    d.a0, d.a1, d.w, d.bias = _ptr(x0), _ptr(x1), _ptr(pw.w), _ptr(b)
+    d.rowvec, d.residual, d.out = _ptr(rowvec), _ptr(residual), _ptr(out)
+    d.c0, d.c1 = c0, c1
+    d.n_img, d.h_in, d.w_in = g.n_img, g.h_in, g.w_in
+    d.h_virt, d.w_virt = g.h_virt or g.h_in, g.w_virt or g.w_in
+    d.h_out, d.w_out = g.h_out, g.w_out
+    d.kh, d.kw, d.stride, d.pad_h, d.pad_w = pw.kh, pw.kw, g.stride, g.pad_h, g.pad_w
+    d.n_out, d.n_pad, d.k_pad = pw.n_out, pw.n_pad, pw.k_pad
+    d.rowvec_div = rowvec_div
+    d.ldo = out.stride(0)
+    d.ldr = 0 if residual is None else residual.stride(0)
+    d.act, d.geglu, d.bias_per_row = act, int(pw.geglu), int(bias_per_row)
+    d.dtype, d.out_dtype, d.out_scale = _DT[x0.dtype], _DT[odt], out_scale
+    _run(lib.aa_conv_gemm, C.byref(d), _stream(x0))
+    return out
+
+
+# ------------------------------------------------------------------------------------- norms
+def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_groups_img: int,
+              tokens_per_group: int, num_groups: int = 32, eps: float = 1e-5, silu: bool = False,
+              x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.get()
+    _check(x0, x1, gamma, beta)
+    c0 = x0.shape[-1]
+    c1 = 0 if x1 is None else x1.shape[-1]
+    y = torch.empty(n_groups_img * tokens_per_group, c0 + c1, dtype=x0.dtype, device=x0.device)
+    d = AaGroupNorm()
+    d.x0, d.x1, d.gamma, d.beta, d.y = _ptr(x0), _ptr(x1), _ptr(gamma), _ptr(beta), _ptr(y)
+    d.c0, d.c1 = c0, c1
+    d.n_groups_img, d.tokens_per_group, d.num_groups = n_groups_img, tokens_per_group, num_groups
+    d.silu, d.dtype, d.eps = int(silu), _DT[x0.dtype], eps
+    nbytes = lib.aa_groupnorm_workspace(C.byref(d))
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x0.device)
+    _run(lib.aa_groupnorm, C.byref(d), _ptr(ws), nbytes, _stream(x0))
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    lib = _lib.get()
+    _check(x, gamma, beta)
+    y = torch.empty_like(x)
+    _run(lib.aa_layernorm, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), x.shape[0], x.shape[1], eps,
+         _DT[x.dtype], _stream(x))
+    return y
+
+
+# ------------------------------------------------------------------------------------- attention
+def _operand(t: torch.Tensor, col0: int, outer_stride: int, inner_stride: int, pos_stride: int, outer_div: int = 1):
+    o = AaAttnOperand()
+    o.ptr, o.ld, o.col0 = _ptr(t), t.stride(0), col0
+    o.outer_stride, o.inner_stride, o.pos_stride, o.outer_div = outer_stride, inner_stride, pos_stride, outer_div
+    return o
+
+
+def attention(q: torch.Tensor, q_col0: int, k: torch.Tensor, k_col0: int, v: torch.Tensor, v_col0: int,
+              heads: int, n_outer: int, n_inner: int, q_len: int, kv_len: int,
+              q_strides, kv_strides, kv_outer_div: int = 1, scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(q k^T * scale) v for every (outer, inner, head).  `*_strides` = (outer, inner, pos)
+    row strides of the token matrices; output rows use the q addressing, columns [0, heads*64)."""
+    lib = _lib.get()
+    _check(q, k, v)
+    out = torch.empty(q.shape[0], heads * 64, dtype=q.dtype, device=q.device)
+    d = AaAttention()
+    d.q = _operand(q, q_col0, *q_strides)
+    d.k = _operand(k, k_col0, *kv_strides, outer_div=kv_outer_div)
+    d.v = _operand(v, v_col0, *kv_strides, outer_div=kv_outer_div)
+    d.o = _operand(out, 0, *q_strides)
+    d.n_outer, d.n_inner, d.heads, d.head_dim = n_outer, n_inner, heads, 64
+    d.q_len, d.kv_len, d.dtype = q_len, kv_len, _DT[q.dtype]
+    d.scale = 0.125 if scale is None else scale
+    _run(lib.aa_attention, C.byref(d), _stream(q))
+    return out
+
+
+def softmax_rows(x: torch.Tensor, dtype) -> torch.Tensor:
+    lib = _lib.get()
+    _check(x)
+    assert x.dtype == torch.float32
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _run(lib.aa_softmax_rows, _ptr(x), _ptr(y), x.shape[0], x.shape[1], _DT[dtype], _stream(x))
+    return y
+
+
+def cfg_dpm_step(eps_uncond, eps_text, latents, x0_prev, latents_lp, guidance, sigma_s, alpha_s, c_x, c_d0, c_d1):
+    lib = _lib.get()
+    _check(eps_uncond, eps_text, latents, x0_prev, latents_lp)
+    d = AaDpmStep()
+    d.eps_uncond, d.eps_text = _ptr(eps_uncond), _ptr(eps_text)
+    d.latents, d.x0_prev, d.latents_lp = _ptr(latents), _ptr(x0_prev), _ptr(latents_lp)
+    d.n = latents.numel()
+    d.guidance, d.sigma_s, d.alpha_s, d.c_x, d.c_d0, d.c_d1 = guidance, sigma_s, alpha_s, c_x, c_d0, c_d1
+    d.dtype = _DT[eps_uncond.dtype]
+    _run(lib.aa_cfg_dpm_step, C.byref(d), _stream(latents))

@@ -1,0 +1,175 @@
+/*
+ * aa_mi355.h -- C ABI of libaa_mi355.so: the MI355X (gfx950) kernels behind the animate-anything
+ * denoising hot path (UNet3DConditionModel forward + AutoencoderKL encode/decode).
+ *
+ * The reference has no native/FFI boundary: its arithmetic is reached through Python modules of
+ * diffusers==0.24.0.  Each entry point below therefore cites the reference
+ * Python operation(s) it replaces.  Binding: ctypes (animate_anything_amd/_lib.py); see INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch allocator); the library never
+ *    allocates, frees or retains device memory;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, nothing
+ *    synchronises, so calls are hipGraph-capturable;
+ *  - return 0 on success, a negative AA_E_* code otherwise; aa_last_error() gives the message
+ *    (thread-local); no C++ exception crosses the ABI;
+ *  - activations are channels-last: an image batch [N,C,H,W] of the reference is stored as
+ *    [N*H*W tokens][C] (C contiguous); a clip [B,C,T,H,W] as [(B*T)*H*W][C];
+ *  - dtype AA_F16 / AA_BF16 selects the storage type of activations and weights; all accumulation
+ *    and all statistics are fp32.
+ */
+#ifndef AA_MI355_H
+#define AA_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AA_VERSION 100
+
+enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
+enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
+enum { AA_ACT_NONE = 0, AA_ACT_SILU = 1 };
+
+int aa_version(void);
+const char* aa_last_error(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * aa_conv_gemm: out[m, n] = epilogue( sum_k A(m, k) * W[n, k] )  on the matrix cores.
+ *
+ * A is gathered on the fly from a channels-last activation (implicit GEMM):
+ *   m -> (img, y, x) over an [n_img, h_out, w_out] output grid,
+ *   k -> (tap = dy*kw+dx, channel c), source pixel (y*stride - pad_h + dy, x*stride - pad_w + dx)
+ *   of a virtual [h_virt, w_virt] grid that is the nearest-neighbour resize of the stored
+ *   [h_in, w_in] grid (h_virt == h_in when there is no upsample); out-of-range taps read zero.
+ *   Channels c < c0 come from a0, the rest from a1 (channel concat without a copy).
+ * One entry point covers every contraction of the path:
+ *   nn.Linear / Conv2d 1x1      kh=kw=1               (diffusers Attention.to_q/k/v/out, FeedForward,
+ *                                                     proj_in/out, time_emb_proj, conv_shortcut)
+ *   nn.Conv2d 3x3               kh=kw=3, pad 1        (ResnetBlock2D.conv1/2, conv_in2, conv_out;
+ *                                                     reference unet_3d_condition_mask.py:140-142,264)
+ *   Downsample2D                stride 2              (unet_3d_blocks.py:476,591)
+ *   Upsample2D                  h_virt = 2*h_in or output_size (unet_3d_blocks.py:709,819,761-763)
+ *   nn.Conv3d (3,1,1)           kh=3, kw=1 with h=T, w=H*W  (TemporalConvLayer, unet_3d_blocks.py:276..808)
+ * Epilogue, in order: + bias[n] (or bias[m]); + rowvec[m / rowvec_div, n] (time embedding,
+ * diffusers ResnetBlock2D); activation; GEGLU pairing (diffusers GEGLU: value * gelu_erf(gate));
+ * + residual[m, n]; * out_scale; store as `out_dtype`.
+ * W is pre-packed by the host: [n_pad, k_pad] row-major, k ordered (tap, channel), zero padded,
+ * and for GEGLU interleaved in blocks of 32 value rows / 32 gate rows.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct AaConvGemm {
+    const void* a0;
+    const void* a1;        /* NULL when c1 == 0 */
+    const void* w;         /* packed weights [n_pad][k_pad] */
+    const void* bias;      /* [n_out] (or [M] when bias_per_row), storage dtype, may be NULL */
+    const void* rowvec;    /* [M / rowvec_div][n_out], storage dtype, may be NULL */
+    const void* residual;  /* [M][ldr], storage dtype, may be NULL */
+    void* out;             /* [M][ldo] */
+    int32_t c0, c1;
+    int32_t n_img, h_in, w_in, h_virt, w_virt, h_out, w_out;
+    int32_t kh, kw, stride, pad_h, pad_w;
+    int32_t n_out;         /* logical output columns (before GEGLU halving) */
+    int32_t n_pad, k_pad;  /* packed weight extents: n_pad % 128 == 0 (or 64), k_pad % 64 == 0 */
+    int32_t rowvec_div;
+    int32_t ldo, ldr;
+    int32_t act;           /* AA_ACT_* */
+    int32_t geglu;         /* 1: columns are (32 value | 32 gate) blocks, output has n_out/2 columns */
+    int32_t bias_per_row;
+    int32_t dtype;         /* AA_F16 | AA_BF16: activations + weights */
+    int32_t out_dtype;     /* AA_F16 | AA_BF16 (== dtype) or AA_F32 */
+    float out_scale;
+} AaConvGemm;
+
+int aa_conv_gemm(const AaConvGemm* d, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * aa_groupnorm: y = [silu]( (x - mean) * rstd * gamma + beta ), statistics per (image group, channel
+ * group) over `tokens_per_group` consecutive tokens x (C / num_groups) channels.
+ *   tokens_per_group = H*W     -> nn.GroupNorm on [N,C,H,W]   (ResnetBlock2D.norm1/2, Transformer2DModel.norm,
+ *                                 conv_norm_out; reference unet_3d_condition_mask.py:255-257)
+ *   tokens_per_group = T*H*W   -> nn.GroupNorm on [B,C,T,H,W] (TemporalConvLayer, TransformerTemporalModel.norm)
+ * x may be the channel concat of two tensors (up-block resnets, reference unet_3d_blocks.py:731,828).
+ * `workspace` holds fp32 partial sums: aa_groupnorm_workspace() bytes.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct AaGroupNorm {
+    const void* x0;
+    const void* x1;      /* NULL when c1 == 0 */
+    const void* gamma;   /* [c0+c1] storage dtype */
+    const void* beta;
+    void* y;             /* [tokens][c0+c1] */
+    int32_t c0, c1;
+    int32_t n_groups_img;      /* number of statistic groups along the token axis */
+    int32_t tokens_per_group;
+    int32_t num_groups;        /* channel groups (32) */
+    int32_t silu;
+    int32_t dtype;
+    float eps;
+} AaGroupNorm;
+
+size_t aa_groupnorm_workspace(const AaGroupNorm* d);
+int aa_groupnorm(const AaGroupNorm* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* aa_layernorm: nn.LayerNorm(C, eps) over the last dim of [rows][C]
+ * (diffusers BasicTransformerBlock.norm1/2/3). */
+int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y,
+                 int64_t rows, int32_t channels, float eps, int32_t dtype, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * aa_attention: O = softmax(Q K^T * scale) V per (sequence, head), head_dim 64, flash-style
+ * (scores never leave the chip).  Replaces F.scaled_dot_product_attention as selected by the
+ * reference's AttnProcessor2_0 (train.py:124-138).
+ * A sequence is addressed as (outer o, inner i); the row of position p in operand X is
+ *     (o / X.outer_div) * X.outer_stride + i * X.inner_stride + p * X.pos_stride      [tokens]
+ * and element (head h, d) sits at column X.col0 + h*64 + d of a row of X.ld elements:
+ *   spatial self-attention   outer = image, inner = 1,      pos_stride = 1
+ *   temporal self-attention  outer = clip,  inner = pixel,  pos_stride = H*W  (no permute copies)
+ *   text cross-attention     K/V outer_div = frames per clip (text K/V computed once per clip)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct AaAttnOperand {
+    const void* ptr;
+    int64_t outer_stride, inner_stride, pos_stride;   /* in rows (tokens) */
+    int32_t ld, col0, outer_div, _pad;
+} AaAttnOperand;
+
+typedef struct AaAttention {
+    AaAttnOperand q, k, v, o;   /* o.ptr is written */
+    int32_t n_outer, n_inner, heads, head_dim;
+    int32_t q_len, kv_len;
+    int32_t dtype;
+    float scale;
+} AaAttention;
+
+int aa_attention(const AaAttention* d, void* stream);
+
+/* aa_softmax_rows: y[r, :] = softmax(x[r, :]) for fp32 scores (VAE mid-block single-head
+ * attention, head_dim 512, where scores are materialised: diffusers Attention with
+ * upcast_softmax). x fp32 [rows][cols], y storage dtype [rows][cols]. */
+int aa_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int32_t dtype, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * aa_cfg_dpm_step: fused classifier-free guidance + DPM-Solver++(2M) update of one denoising
+ * step (reference models/pipeline.py:179-192 + diffusers DPMSolverMultistepScheduler.step):
+ *   eps = eps_uncond + g * (eps_text - eps_uncond);  x0 = (x - sigma_s*eps) / alpha_s
+ *   x' = c_x * x - c_d0 * x0 - c_d1 * (x0 - x0_prev);  x0_prev <- x0
+ * all tensors fp32 or storage dtype element streams of `n` elements.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct AaDpmStep {
+    const void* eps_uncond;   /* storage dtype [n] */
+    const void* eps_text;     /* storage dtype [n] (== eps_uncond when guidance is off) */
+    void* latents;            /* fp32 [n], updated in place */
+    void* x0_prev;            /* fp32 [n], updated in place */
+    void* latents_lp;         /* storage dtype copy of the new latents [n] (next UNet input) */
+    int64_t n;
+    float guidance, sigma_s, alpha_s, c_x, c_d0, c_d1;
+    int32_t dtype;
+} AaDpmStep;
+
+int aa_cfg_dpm_step(const AaDpmStep* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AA_MI355_H */

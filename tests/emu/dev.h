@@ -1,0 +1,182 @@
+// Host-side SIMT emulator standing in for csrc/kernels/device/dev.h.  TEST INFRASTRUCTURE ONLY.
+//
+// Lets the kernel bodies in animate_anything_amd/csrc/kernels/*.h run on the CPU (this container has
+// no GPU) so their index arithmetic, LDS choreography and MFMA fragment bookkeeping can be checked
+// against numpy before a GPU-minute is spent.  Every thread of a workgroup is a ucontext fiber;
+// __syncthreads() and the wave64 collectives (MFMA, shuffles) are rendezvous points.  The 32x32x16
+// MFMA is modelled with the gfx950 register layout documented in cdna_hip_programming.md section 3.
+// It models semantics only - no timing, no bank conflicts, no memory-ordering hazards.
+#pragma once
+#include <ucontext.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+#include "types.h"
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace emu {
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    bool done = false;
+    dim3 tid;
+};
+struct Block {
+    std::vector<Fiber> fibers;
+    ucontext_t sched;
+    int cur = 0;
+    int alive = 0;
+    int bar_count = 0;
+    unsigned bar_gen = 0;
+    std::vector<int> wave_count;
+    std::vector<unsigned> wave_gen;
+    std::vector<std::vector<const void*>> wave_slots;   // [wave][lane]
+    std::vector<char> lds;
+    std::function<void()> body;
+};
+inline Block*& blk() { static Block* b = nullptr; return b; }
+}  // namespace emu
+
+inline dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace emu {
+inline void yield() {
+    Block* b = blk();
+    Fiber& f = b->fibers[b->cur];
+    swapcontext(&f.ctx, &b->sched);
+}
+inline int linear_tid() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
+inline void block_barrier() {
+    Block* b = blk();
+    const unsigned g = b->bar_gen;
+    if (++b->bar_count == b->alive) { b->bar_count = 0; ++b->bar_gen; }
+    else while (b->bar_gen == g) yield();
+}
+inline void wave_barrier() {
+    Block* b = blk();
+    const int w = linear_tid() >> 6;
+    const int lanes = std::min<int>(64, (int)b->fibers.size() - 64 * w);
+    const unsigned g = b->wave_gen[w];
+    if (++b->wave_count[w] == lanes) { b->wave_count[w] = 0; ++b->wave_gen[w]; }
+    else while (b->wave_gen[w] == g) yield();
+}
+// publish a pointer to this lane's operand, wait for the whole wave, let `use` read any lane's
+// operand, wait again so no lane's stack storage disappears while others still read it.
+template <typename F>
+inline void wave_collective(const void* mine, F&& use) {
+    Block* b = blk();
+    const int t = linear_tid();
+    b->wave_slots[t >> 6][t & 63] = mine;
+    wave_barrier();
+    use(b->wave_slots[t >> 6]);
+    wave_barrier();
+}
+inline void fiber_entry() {
+    Block* b = blk();
+    b->body();
+    b->fibers[b->cur].done = true;
+    --b->alive;
+    if (b->alive > 0 && b->bar_count == b->alive) { b->bar_count = 0; ++b->bar_gen; }
+    swapcontext(&b->fibers[b->cur].ctx, &b->sched);
+}
+// Run `body` once per thread of a grid x block launch with `lds_bytes` of dynamic LDS per block.
+inline void launch(dim3 grid, dim3 block, size_t lds_bytes, std::function<void()> body) {
+    gridDim = grid; blockDim = block;
+    const int nthreads = block.x * block.y * block.z;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                Block b;
+                blk() = &b;
+                b.body = body;
+                b.lds.assign(lds_bytes + 64, (char)0xAB);
+                b.fibers.resize(nthreads);
+                const int nw = (nthreads + 63) / 64;
+                b.wave_count.assign(nw, 0); b.wave_gen.assign(nw, 0);
+                b.wave_slots.assign(nw, std::vector<const void*>(64, nullptr));
+                b.alive = nthreads;
+                for (int t = 0; t < nthreads; ++t) {
+                    Fiber& f = b.fibers[t];
+                    f.stack.resize(256 * 1024);
+                    f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack.data();
+                    f.ctx.uc_stack.ss_size = f.stack.size();
+                    f.ctx.uc_link = nullptr;
+                    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+                }
+                blockIdx = dim3(bx, by, bz);
+                while (b.alive > 0)
+                    for (int t = 0; t < nthreads; ++t) {
+                        if (b.fibers[t].done) continue;
+                        b.cur = t;
+                        threadIdx = b.fibers[t].tid;
+                        swapcontext(&b.sched, &b.fibers[t].ctx);
+                    }
+                blk() = nullptr;
+            }
+}
+}  // namespace emu
+
+inline void __syncthreads() { emu::block_barrier(); }
+inline char* dyn_smem() {
+    char* p = emu::blk()->lds.data();
+    return p + ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15);
+}
+inline float __expf(float x) { return std::exp(x); }
+inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+using std::min;
+using std::max;
+inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+
+inline float wave_shfl_xor(float v, int mask) {
+    float out = 0.0f;
+    emu::wave_collective(&v, [&](const std::vector<const void*>& s) {
+        out = *static_cast<const float*>(s[(emu::linear_tid() & 63) ^ mask]);
+    });
+    return out;
+}
+inline float wave_shfl(float v, int src) {
+    float out = 0.0f;
+    emu::wave_collective(&v, [&](const std::vector<const void*>& s) { out = *static_cast<const float*>(s[src]); });
+    return out;
+}
+
+template <typename T>
+inline f32x16 emu_mfma_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
+    struct Ops { u32x4 a, b; } mine{a, b};
+    f32x16 d = c;
+    emu::wave_collective(&mine, [&](const std::vector<const void*>& s) {
+        const int lane = emu::linear_tid() & 63;
+        const int j = lane & 31;
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float acc = c[r];
+            for (int half = 0; half < 2; ++half) {
+                Pack8<T> pa, pb;
+                pa.raw = static_cast<const Ops*>(s[i + 32 * half])->a;
+                pb.raw = static_cast<const Ops*>(s[j + 32 * half])->b;
+                for (int e = 0; e < 8; ++e) acc += (float)pa.e[e] * (float)pb.e[e];
+            }
+            d[r] = acc;
+        }
+    });
+    return d;
+}
+inline f32x16 mfma_32x32x16(f16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<f16_t>(a, b, c); }
+inline f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<bf16_t>(a, b, c); }

@@ -1,0 +1,178 @@
+"""Kernel bodies run on the CPU SIMT emulator (tests/emu) against plain fp32 torch references.
+
+These tests exercise the SAME kernel sources and the SAME host-side packing/descriptor code as the
+GPU path; they validate index arithmetic, LDS staging and MFMA fragment bookkeeping (not timing and
+not the hardware itself -- the `-m gpu` tests do that)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from animate_anything_amd import ops
+from animate_anything_amd._lib import AA_ACT_SILU
+
+DT = torch.float16
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DT)
+
+
+def close(a, b, tol=2e-2):
+    a, b = a.float(), b.float()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-6
+    assert err <= tol * max(1.0, ref), f"max err {err} (ref max {ref})"
+
+
+def nhwc(x):   # [N,C,H,W] -> tokens x C
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def test_linear_bias_silu_residual(emu):
+    M, K, N = 200, 96, 80
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, scale=0.1, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    pw = ops.pack_weight(w, b)
+    assert pw.w.shape == (128, 128)
+    y = ops.conv_gemm(x, pw, ops.linear_geom(M), residual=r, act=AA_ACT_SILU)
+    ref = F.silu(x.float() @ w.float().t() + b.float()) + r.float()
+    close(y, ref)
+
+
+def test_linear_bn64_fp32_out_scale_rowbias(emu):
+    M, K, N = 130, 64, 192
+    x, w, b = rnd(M, K, seed=5), rnd(N, K, scale=0.1, seed=6), rnd(M, seed=7)
+    pw = ops.pack_weight(w)
+    assert pw.n_pad == 192
+    y = ops.conv_gemm(x, pw, ops.linear_geom(M), bias=b, bias_per_row=True, out_dtype=torch.float32, out_scale=0.5)
+    assert y.dtype == torch.float32
+    close(y, 0.5 * (x.float() @ w.float().t() + b.float()[:, None]))
+
+
+def test_geglu(emu):
+    M, K, D = 70, 64, 64
+    x, w, b = rnd(M, K, seed=8), rnd(2 * D, K, scale=0.2, seed=9), rnd(2 * D, seed=10)
+    y = ops.conv_gemm(x, ops.pack_weight(w, b, geglu=True), ops.linear_geom(M))
+    h = x.float() @ w.float().t() + b.float()
+    close(y, h[:, :D] * F.gelu(h[:, D:]))
+
+
+@pytest.mark.parametrize("stride,pad,up_to", [(1, 1, None), (2, 1, None), (2, 0, None), (1, 1, (10, 14)), (1, 1, (9, 13))])
+def test_conv3x3(emu, stride, pad, up_to):
+    n, h, w, cin, cout = 2, 5, 7, 16, 72
+    x, wt, b = rnd(n, cin, h, w, seed=11), rnd(cout, cin, 3, 3, scale=0.1, seed=12), rnd(cout, seed=13)
+    g = ops.conv3x3_geom(n, h, w, stride=stride, pad=pad, up_to=up_to)
+    y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g)
+    xr = x.float()
+    if up_to is not None:
+        xr = F.interpolate(xr, size=up_to, mode="nearest")
+    if pad == 0:
+        xr = F.pad(xr, (0, 1, 0, 1))
+    ref = F.conv2d(xr, wt.float(), b.float(), stride=stride, padding=pad)
+    assert (g.h_out, g.w_out) == tuple(ref.shape[2:])
+    close(y, nhwc(ref))
+
+
+def test_conv3x3_concat_rowvec_cin5(emu):
+    n, h, w, cout = 3, 4, 6, 64
+    a, bsrc = rnd(n, 8, h, w, seed=14), rnd(n, 16, h, w, seed=15)
+    wt, b, temb = rnd(cout, 24, 3, 3, scale=0.1, seed=16), rnd(cout, seed=17), rnd(n, cout, seed=18)
+    y = ops.conv_gemm(nhwc(a), ops.pack_weight(wt, b), ops.conv3x3_geom(n, h, w), x1=nhwc(bsrc),
+                      rowvec=temb, rowvec_div=h * w)
+    ref = F.conv2d(torch.cat([a, bsrc], 1).float(), wt.float(), b.float(), padding=1) + temb.float()[:, :, None, None]
+    close(y, nhwc(ref))
+    # conv_in2-style: 5 input channels zero-padded to 8 in the activation and the packed weight
+    x5, w5 = rnd(n, 5, h, w, seed=19), rnd(cout, 5, 3, 3, scale=0.2, seed=20)
+    pw = ops.pack_weight(w5, b)
+    assert pw.cin == 8 and pw.k_pad == 128
+    y5 = ops.conv_gemm(nhwc(F.pad(x5, (0, 0, 0, 0, 0, 3))), pw, ops.conv3x3_geom(n, h, w))
+    close(y5, nhwc(F.conv2d(x5.float(), w5.float(), b.float(), padding=1)))
+
+
+def test_temporal_conv(emu):
+    clips, frames, hh, ww, c = 2, 5, 2, 3, 16
+    x = rnd(clips, c, frames, hh, ww, seed=21)
+    wt, b = rnd(c, c, 3, 1, 1, scale=0.2, seed=22), rnd(c, seed=23)
+    tok = x.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous()
+    res = rnd(tok.shape[0], c, seed=24)
+    y = ops.conv_gemm(tok, ops.pack_weight(wt, b), ops.tconv_geom(clips, frames, hh * ww), residual=res)
+    ref = F.conv3d(x.float(), wt.float(), b.float(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, c) + res.float()
+    close(y, ref)
+
+
+@pytest.mark.parametrize("c0,c1,groups,frames", [(64, 0, 32, 1), (40, 24, 32, 1), (80, 0, 8, 3), (2560, 0, 32, 1)])
+def test_groupnorm(emu, c0, c1, groups, frames):
+    n, hw = 3 * frames, 37 if c0 < 1000 else 3
+    C = c0 + c1
+    x = rnd(n, C, hw, 1, seed=25) * 2 + 0.5
+    gamma, beta = rnd(C, seed=26), rnd(C, seed=27)
+    tok = nhwc(x)
+    x0, x1 = (tok, None) if c1 == 0 else (tok[:, :c0].contiguous(), tok[:, c0:].contiguous())
+    y = ops.groupnorm(x0, gamma, beta, n // frames, frames * hw, groups, eps=1e-5, silu=True, x1=x1)
+    x5 = x.float().reshape(n // frames, frames, C, hw).permute(0, 2, 1, 3)          # [B,C,T,HW]
+    ref = F.silu(F.group_norm(x5, groups, gamma.float(), beta.float(), 1e-5))
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, C)
+    close(y, ref)
+
+
+@pytest.mark.parametrize("C", [64, 320, 1280])
+def test_layernorm(emu, C):
+    x, g, b = rnd(10, C, seed=28) * 3 + 1, rnd(C, seed=29), rnd(C, seed=30)
+    close(ops.layernorm(x, g, b, 1e-5), F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5))
+
+
+def sdpa(q, k, v):
+    s = q.float() @ k.float().transpose(-1, -2) / math.sqrt(q.shape[-1])
+    return s.softmax(-1) @ v.float()
+
+
+def test_attention_spatial(emu):
+    n, heads, L = 2, 2, 100
+    C = heads * 64
+    qkv = rnd(n * L, 3 * C, seed=31)
+    o = ops.attention(qkv, 0, qkv, C, qkv, 2 * C, heads, n, 1, L, L, (L, 0, 1), (L, 0, 1))
+    x = qkv.reshape(n, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = sdpa(x[0], x[1], x[2]).permute(0, 2, 1, 3).reshape(n * L, C)
+    close(o, ref, tol=1e-2)
+
+
+def test_attention_cross_text(emu):
+    clips, frames, heads, L, Lt = 2, 2, 1, 40, 77
+    C = heads * 64
+    q = rnd(clips * frames * L, C, seed=32)
+    kv = rnd(clips * Lt, 2 * C, seed=33)
+    o = ops.attention(q, 0, kv, 0, kv, C, heads, clips * frames, 1, L, Lt, (L, 0, 1), (Lt, 0, 1), kv_outer_div=frames)
+    qq = q.reshape(clips, frames, L, heads, 64).permute(0, 1, 3, 2, 4)
+    kk = kv.reshape(clips, 1, Lt, 2, heads, 64).permute(3, 0, 1, 4, 2, 5)
+    ref = sdpa(qq, kk[0], kk[1]).permute(0, 1, 3, 2, 4).reshape(-1, C)
+    close(o, ref, tol=1e-2)
+
+
+def test_attention_temporal(emu):
+    clips, frames, hw, heads = 2, 5, 6, 2
+    C = heads * 64
+    qkv = rnd(clips * frames * hw, 3 * C, seed=34)
+    st = (frames * hw, 1, hw)
+    o = ops.attention(qkv, 0, qkv, C, qkv, 2 * C, heads, clips, hw, frames, frames, st, st)
+    x = qkv.reshape(clips, frames, hw, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)       # [3,b,hw,h,T,d]
+    ref = sdpa(x[0], x[1], x[2]).permute(0, 3, 1, 2, 4).reshape(-1, C)                 # -> [b,T,hw,h,d]
+    close(o, ref, tol=1e-2)
+
+
+def test_softmax_rows_and_dpm_step(emu):
+    g = torch.Generator().manual_seed(35)
+    s = torch.randn(5, 300, generator=g) * 4
+    close(ops.softmax_rows(s, DT), s.softmax(-1), tol=2e-3)
+    n = 1000
+    eu, et = rnd(n, seed=36), rnd(n, seed=37)
+    x, x0p = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    lp = torch.empty(n, dtype=DT)
+    xr, x0r = x.clone(), x0p.clone()
+    ops.cfg_dpm_step(eu, et, x, x0p, lp, 9.0, 0.7, 0.71, 0.9, -0.2, -0.05)
+    eps = eu.float() + 9.0 * (et.float() - eu.float())
+    x0 = (xr - 0.7 * eps) / 0.71
+    close(x, 0.9 * xr + 0.2 * x0 + 0.05 * (x0 - x0r), tol=1e-5)
+    close(x0p, x0, tol=1e-5)
+    close(lp, x, tol=2e-3)
