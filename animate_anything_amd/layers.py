@@ -1,0 +1,357 @@
+"""HIP-backed layer library: the diffusers==0.24.0 building blocks the reference composes
+(/root/reference/models/unet_3d_blocks.py:18-20, /root/reference/models/unet_3d_condition_mask.py:22-26),
+re-designed around channels-last token matrices.
+
+Every module keeps the parameter names of its diffusers counterpart (state-dict compatible, SURVEY.md
+Appendix C) but computes through `ops` (libaa_mi355.so).  Activations travel between modules as
+`[tokens, C]` matrices plus a `Grid` describing (clips B, frames T, H, W); nothing is ever permuted:
+the spatial view (image n = b*T+t, pixel) and the temporal view (clip b, pixel, frame) are two ways
+of indexing the same buffer.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import AA_ACT_NONE, AA_ACT_SILU
+
+
+@dataclass(frozen=True)
+class Grid:
+    """Geometry of a token matrix: tokens = clips*frames*h*w, ordered (clip, frame, y, x)."""
+    clips: int
+    frames: int
+    h: int
+    w: int
+
+    @property
+    def images(self):
+        return self.clips * self.frames
+
+    @property
+    def hw(self):
+        return self.h * self.w
+
+    @property
+    def tokens(self):
+        return self.images * self.hw
+
+    def resized(self, h, w):
+        return replace(self, h=h, w=w)
+
+
+class _Packed:
+    """Mixin: caches the kernel-side weight layout; dropped whenever the module is moved/cast."""
+    _pw = None
+
+    def _apply(self, fn, *a, **k):
+        self._pw = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pw = None
+        return super()._load_from_state_dict(*a, **k)
+
+
+def _no_eager(name):
+    raise RuntimeError(f"{name}: this module only runs through the HIP token path of animate_anything_amd")
+
+
+class Linear(_Packed, nn.Linear):
+    def packed(self):
+        if self._pw is None:
+            self._pw = ops.pack_weight(self.weight, self.bias)
+        return self._pw
+
+    def tokens(self, x, **epilogue):
+        return ops.conv_gemm(x, self.packed(), ops.linear_geom(x.shape[0]), **epilogue)
+
+    def forward(self, x):
+        _no_eager("Linear")
+
+
+class Conv2d(_Packed, nn.Conv2d):
+    def packed(self):
+        if self._pw is None:
+            self._pw = ops.pack_weight(self.weight, self.bias)
+        return self._pw
+
+    def tokens(self, x, geom, **epilogue):
+        return ops.conv_gemm(x, self.packed(), geom, **epilogue)
+
+    def forward(self, x):
+        _no_eager("Conv2d")
+
+
+class Conv3d(_Packed, nn.Conv3d):
+    def packed(self):
+        if self._pw is None:
+            self._pw = ops.pack_weight(self.weight, self.bias)
+        return self._pw
+
+    def tokens(self, x, geom, **epilogue):
+        return ops.conv_gemm(x, self.packed(), geom, **epilogue)
+
+    def forward(self, x):
+        _no_eager("Conv3d")
+
+
+class GroupNorm(nn.GroupNorm):
+    def tokens(self, x, n_stat_groups, tokens_per_group, silu=False, x1=None):
+        return ops.groupnorm(x, self.weight, self.bias, n_stat_groups, tokens_per_group, self.num_groups,
+                             self.eps, silu, x1=x1)
+
+    def forward(self, x):
+        _no_eager("GroupNorm")
+
+
+class LayerNorm(nn.LayerNorm):
+    def tokens(self, x):
+        return ops.layernorm(x, self.weight, self.bias, self.eps)
+
+    def forward(self, x):
+        _no_eager("LayerNorm")
+
+
+# ------------------------------------------------------------------------------------- embeddings
+class TimestepEmbedding(nn.Module):
+    """diffusers TimestepEmbedding(act='silu', cond_proj_dim).  `tokens` returns
+    silu(linear_2(...)) when `final_silu` since the only consumers are the resnets'
+    time_emb_proj(silu(temb))."""
+
+    def __init__(self, in_channels, time_embed_dim, cond_proj_dim=None):
+        super().__init__()
+        self.linear_1 = Linear(in_channels, time_embed_dim)
+        self.cond_proj = Linear(cond_proj_dim, in_channels, bias=False) if cond_proj_dim else None
+        self.linear_2 = Linear(time_embed_dim, time_embed_dim)
+
+    def tokens(self, sample, condition=None, final_silu=False):
+        if condition is not None:
+            sample = self.cond_proj.tokens(condition, residual=sample)
+        h = self.linear_1.tokens(sample, act=AA_ACT_SILU)
+        return self.linear_2.tokens(h, act=AA_ACT_SILU if final_silu else AA_ACT_NONE)
+
+
+# ------------------------------------------------------------------------------------- conv blocks
+class ResnetBlock2D(nn.Module):
+    """diffusers ResnetBlock2D.  The input may arrive as two channel-concatenated
+    sources (up-block skip connections) - the concat is never materialised."""
+
+    def __init__(self, in_channels, out_channels=None, temb_channels=1280, eps=1e-5, groups=32,
+                 output_scale_factor=1.0):
+        super().__init__()
+        out_channels = out_channels or in_channels
+        self.norm1 = GroupNorm(groups, in_channels, eps=eps)
+        self.conv1 = Conv2d(in_channels, out_channels, 3, padding=1)
+        self.time_emb_proj = Linear(temb_channels, out_channels) if temb_channels else None
+        self.norm2 = GroupNorm(groups, out_channels, eps=eps)
+        self.conv2 = Conv2d(out_channels, out_channels, 3, padding=1)
+        self.conv_shortcut = Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+        self.output_scale_factor = output_scale_factor
+
+    def tokens(self, x, g: Grid, temb_silu=None, x1=None):
+        geom = ops.conv3x3_geom(g.images, g.h, g.w)
+        h = self.norm1.tokens(x, g.images, g.hw, silu=True, x1=x1)
+        if self.time_emb_proj is not None and temb_silu is not None:
+            tproj = self.time_emb_proj.tokens(temb_silu)                    # [clips, Cout]
+            h = self.conv1.tokens(h, geom, rowvec=tproj, rowvec_div=g.frames * g.hw)
+        else:
+            h = self.conv1.tokens(h, geom)
+        h = self.norm2.tokens(h, g.images, g.hw, silu=True)
+        if self.conv_shortcut is not None:
+            skip = self.conv_shortcut.tokens(x, ops.linear_geom(g.tokens), x1=x1)
+        else:
+            skip = x
+        return self.conv2.tokens(h, geom, residual=skip, out_scale=1.0 / self.output_scale_factor)
+
+
+class TemporalConvLayer(nn.Module):
+    """diffusers TemporalConvLayer: 4 x {GroupNorm over (C/32,T,H,W), SiLU, Conv3d (3,1,1)}
+    + identity.  The clip-wide statistics are one GroupNorm over T*H*W consecutive tokens; the
+    temporal conv is a 3x1 implicit GEMM over the (frame, pixel) grid - no [B,C,T,H,W] permutes."""
+
+    def __init__(self, in_dim, out_dim=None, dropout=0.0):
+        super().__init__()
+        out_dim = out_dim or in_dim
+
+        def stage(cin, cout, with_dropout):
+            mods = [GroupNorm(32, cin), nn.SiLU()] + ([nn.Dropout(dropout)] if with_dropout else [])
+            return nn.Sequential(*mods, Conv3d(cin, cout, (3, 1, 1), padding=(1, 0, 0)))
+
+        self.conv1 = stage(in_dim, out_dim, False)
+        self.conv2 = stage(out_dim, in_dim, True)
+        self.conv3 = stage(out_dim, in_dim, True)
+        self.conv4 = stage(out_dim, in_dim, True)
+        nn.init.zeros_(self.conv4[-1].weight)
+        nn.init.zeros_(self.conv4[-1].bias)
+
+    def tokens(self, x, g: Grid):
+        geom = ops.tconv_geom(g.clips, g.frames, g.hw)
+        h = x
+        for i, seq in enumerate((self.conv1, self.conv2, self.conv3, self.conv4)):
+            h = seq[0].tokens(h, g.clips, g.frames * g.hw, silu=True)
+            h = seq[-1].tokens(h, geom, residual=x if i == 3 else None)
+        return h
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, channels, out_channels=None, padding=1):
+        super().__init__()
+        self.padding = padding
+        self.conv = Conv2d(channels, out_channels or channels, 3, stride=2, padding=padding)
+
+    def tokens(self, x, g: Grid):
+        geom = ops.conv3x3_geom(g.images, g.h, g.w, stride=2, pad=self.padding)
+        return self.conv.tokens(x, geom), g.resized(geom.h_out, geom.w_out)
+
+
+class Upsample2D(nn.Module):
+    """Nearest x2 (or to `output_size`) fused into the 3x3 conv's gather."""
+
+    def __init__(self, channels, out_channels=None):
+        super().__init__()
+        self.conv = Conv2d(channels, out_channels or channels, 3, padding=1)
+
+    def tokens(self, x, g: Grid, output_size=None):
+        up = (2 * g.h, 2 * g.w) if output_size is None else tuple(int(s) for s in output_size)
+        geom = ops.conv3x3_geom(g.images, g.h, g.w, up_to=up)
+        return self.conv.tokens(x, geom), g.resized(*up)
+
+
+# ------------------------------------------------------------------------------------- attention
+class Attention(nn.Module):
+    """diffusers Attention + AttnProcessor2_0, head_dim 64.  Q/K/V of a self-attention
+    come from ONE GEMM against the row-concatenated weights; the text K/V of a cross-attention are
+    computed once per clip (the reference repeats the text per frame, unet_3d_condition_mask.py:421)."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.dim_head, self.inner = heads, dim_head, inner
+        self.is_cross = cross_attention_dim is not None
+        kv_dim = cross_attention_dim or query_dim
+        self.to_q = Linear(query_dim, inner, bias=False)
+        self.to_k = Linear(kv_dim, inner, bias=False)
+        self.to_v = Linear(kv_dim, inner, bias=False)
+        self.to_out = nn.ModuleList([Linear(inner, query_dim), nn.Dropout(0.0)])
+        self._fused = None
+
+    def _apply(self, fn, *a, **k):
+        self._fused = None
+        return super()._apply(fn, *a, **k)
+
+    def fused(self):
+        if self._fused is None:
+            rows = [self.to_k.weight, self.to_v.weight] if self.is_cross else \
+                   [self.to_q.weight, self.to_k.weight, self.to_v.weight]
+            self._fused = ops.pack_weight(torch.cat([r.detach() for r in rows], dim=0))
+        return self._fused
+
+    def text_kv(self, text_tokens):
+        """[clips*L, cross_dim] -> [clips*L, 2*inner] (K | V)."""
+        return ops.conv_gemm(text_tokens, self.fused(), ops.linear_geom(text_tokens.shape[0]))
+
+    def self_tokens(self, normed, residual, g: Grid, temporal: bool):
+        qkv = ops.conv_gemm(normed, self.fused(), ops.linear_geom(normed.shape[0]))
+        c = self.inner
+        if temporal:
+            st = (g.frames * g.hw, 1, g.hw)
+            a = ops.attention(qkv, 0, qkv, c, qkv, 2 * c, self.heads, g.clips, g.hw, g.frames, g.frames, st, st)
+        else:
+            st = (g.hw, 0, 1)
+            a = ops.attention(qkv, 0, qkv, c, qkv, 2 * c, self.heads, g.images, 1, g.hw, g.hw, st, st)
+        return self.to_out[0].tokens(a, residual=residual)
+
+    def cross_tokens(self, normed, residual, g: Grid, kv, kv_len):
+        q = self.to_q.tokens(normed)
+        a = ops.attention(q, 0, kv, 0, kv, self.inner, self.heads, g.images, 1, g.hw, kv_len,
+                          (g.hw, 0, 1), (kv_len, 0, 1), kv_outer_div=g.frames)
+        return self.to_out[0].tokens(a, residual=residual)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+        self._pw = None
+
+    def _apply(self, fn, *a, **k):
+        self._pw = None
+        return super()._apply(fn, *a, **k)
+
+    def tokens(self, x):
+        if self._pw is None:
+            self._pw = ops.pack_weight(self.proj.weight, self.proj.bias, geglu=True)
+        return ops.conv_gemm(x, self._pw, ops.linear_geom(x.shape[0]))
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim)])
+
+    def tokens(self, x, residual):
+        return self.net[2].tokens(self.net[0].tokens(x), residual=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, head_dim, cross_attention_dim=None, double_self_attention=False):
+        super().__init__()
+        self.norm1 = LayerNorm(dim)
+        self.attn1 = Attention(dim, None, heads, head_dim)
+        self.norm2 = LayerNorm(dim)
+        self.attn2 = Attention(dim, None if double_self_attention else cross_attention_dim, heads, head_dim)
+        self.norm3 = LayerNorm(dim)
+        self.ff = FeedForward(dim)
+        self.double_self_attention = double_self_attention
+
+    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0):
+        x = self.attn1.self_tokens(self.norm1.tokens(x), x, g, temporal)
+        if self.attn2.is_cross:
+            kv = self.attn2.text_kv(text)
+            x = self.attn2.cross_tokens(self.norm2.tokens(x), x, g, kv, text_len)
+        else:
+            x = self.attn2.self_tokens(self.norm2.tokens(x), x, g, temporal)
+        return self.ff.tokens(self.norm3.tokens(x), residual=x)
+
+
+class Transformer2DModel(nn.Module):
+    """diffusers Transformer2DModel(use_linear_projection=True)."""
+
+    def __init__(self, heads, head_dim, in_channels, cross_attention_dim=1024, norm_num_groups=32):
+        super().__init__()
+        inner = heads * head_dim
+        self.norm = GroupNorm(norm_num_groups, in_channels, eps=1e-6)
+        self.proj_in = Linear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, head_dim, cross_attention_dim)])
+        self.proj_out = Linear(inner, in_channels)
+
+    def tokens(self, x, g: Grid, text, text_len):
+        h = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw))
+        for blk in self.transformer_blocks:
+            h = blk.tokens(h, g, temporal=False, text=text, text_len=text_len)
+        return self.proj_out.tokens(h, residual=x)
+
+
+class TransformerTemporalModel(nn.Module):
+    """diffusers TransformerTemporalModel(double_self_attention=True): clip-wide
+    GroupNorm, then a transformer whose sequences are the T frames of one pixel (strided rows)."""
+
+    def __init__(self, heads, head_dim, in_channels, norm_num_groups=32):
+        super().__init__()
+        inner = heads * head_dim
+        self.norm = GroupNorm(norm_num_groups, in_channels, eps=1e-6)
+        self.proj_in = Linear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, heads, head_dim, None, double_self_attention=True)])
+        self.proj_out = Linear(inner, in_channels)
+
+    def tokens(self, x, g: Grid):
+        h = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw))
+        for blk in self.transformer_blocks:
+            h = blk.tokens(h, g, temporal=True)
+        return self.proj_out.tokens(h, residual=x)

@@ -19,6 +19,10 @@ from ._lib import (AA_ACT_NONE, AA_ACT_SILU, AA_BF16, AA_F16, AA_F32, AaAttentio
 
 _DT = {torch.float16: AA_F16, torch.bfloat16: AA_BF16, torch.float32: AA_F32}
 
+# bench.py sets this to a list to record every contraction launch of one step (descriptor + the
+# tensors that keep its pointers alive) so the dominant kernel can be re-timed in isolation.
+TRACE = None
+
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
@@ -182,6 +186,8 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.act, d.geglu, d.bias_per_row = act, int(pw.geglu), int(bias_per_row)
     d.dtype, d.out_dtype, d.out_scale = _DT[x0.dtype], _DT[odt], out_scale
     _run(lib.aa_conv_gemm, C.byref(d), _stream(x0))
+    if TRACE is not None:
+        TRACE.append((d, (x0, x1, pw, b, rowvec, residual, out)))
     return out
 
 

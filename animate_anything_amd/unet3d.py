@@ -1,0 +1,394 @@
+"""UNet3DConditionModel on MI355X: drop-in for the reference's
+/root/reference/models/unet_3d_condition_mask.py:54-526 (module) and the five block classes of
+/root/reference/models/unet_3d_blocks.py:234-842, inference branches.
+
+Same constructor arguments, same `forward` signature / return type, same diffusers state-dict keys
+(SURVEY.md Appendix C); the arithmetic is the HIP token path of `layers.py`.  The whole denoising
+forward between the NC(T)HW boundary tensors is a chain of libaa_mi355.so launches on torch's
+current stream, so it can be captured in a hipGraph (`enable_graph`).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .layers import (Conv2d, Downsample2D, Grid, GroupNorm, Linear, ResnetBlock2D, TemporalConvLayer,
+                     TimestepEmbedding, Transformer2DModel, TransformerTemporalModel, Upsample2D)
+
+
+@dataclass
+class UNet3DConditionOutput:
+    """reference unet_3d_condition_mask.py:43-51."""
+    sample: torch.Tensor
+
+
+def timestep_sinusoid(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): fp32 [len(t), dim]."""
+    half = dim // 2
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    arg = t.reshape(-1).float()[:, None] * freq[None, :]
+    return torch.cat([arg.cos(), arg.sin()], dim=-1)
+
+
+class _Stage(nn.Module):
+    """One resolution stage; per-layer order of the reference inference branches:
+    resnet -> temp_conv -> spatial transformer -> temporal transformer
+    (unet_3d_blocks.py:514-526, 747-759; without attention :606-609, :833-836)."""
+
+    def __init__(self, res_io, temb_channels, eps, groups, heads=None, head_dim=None, cross_attention_dim=None,
+                 down=None, up=False):
+        super().__init__()
+        self.has_cross_attention = heads is not None
+        self.gradient_checkpointing = False
+        self.resnets = nn.ModuleList([ResnetBlock2D(i, o, temb_channels, eps=eps, groups=groups) for i, o in res_io])
+        self.temp_convs = nn.ModuleList([TemporalConvLayer(o, o, dropout=0.1) for _, o in res_io])
+        if self.has_cross_attention:
+            self.attentions = nn.ModuleList(
+                [Transformer2DModel(heads, head_dim, o, cross_attention_dim, groups) for _, o in res_io])
+            self.temp_attentions = nn.ModuleList(
+                [TransformerTemporalModel(heads, head_dim, o, groups) for _, o in res_io])
+        out_ch = res_io[-1][1]
+        self.downsamplers = nn.ModuleList([Downsample2D(out_ch, out_ch, padding=down)]) if down is not None else None
+        self.upsamplers = nn.ModuleList([Upsample2D(out_ch, out_ch)]) if up else None
+
+    def _layer(self, i, x, g, temb_silu, text, text_len, skip=None):
+        x = self.resnets[i].tokens(x, g, temb_silu, x1=skip)
+        if g.frames > 1:
+            x = self.temp_convs[i].tokens(x, g)
+        if self.has_cross_attention:
+            x = self.attentions[i].tokens(x, g, text, text_len)
+            if g.frames > 1:
+                x = self.temp_attentions[i].tokens(x, g)
+        return x
+
+
+class _DownStage(_Stage):
+    def tokens(self, x, g, temb_silu, text, text_len):
+        outs = []
+        for i in range(len(self.resnets)):
+            x = self._layer(i, x, g, temb_silu, text, text_len)
+            outs.append((x, g))
+        if self.downsamplers is not None:
+            x, g = self.downsamplers[0].tokens(x, g)
+            outs.append((x, g))
+        return x, g, outs
+
+
+class CrossAttnDownBlock3D(_DownStage):
+    """reference unet_3d_blocks.py:389-536."""
+
+
+class DownBlock3D(_DownStage):
+    """reference unet_3d_blocks.py:539-619."""
+
+
+class _UpStage(_Stage):
+    def tokens(self, x, g, skips, temb_silu, text, text_len, upsample_size=None):
+        for i in range(len(self.resnets)):
+            skip, _ = skips.pop()
+            x = self._layer(i, x, g, temb_silu, text, text_len, skip=skip)     # cat([x, skip]) is implicit
+        if self.upsamplers is not None:
+            x, g = self.upsamplers[0].tokens(x, g, upsample_size)
+        return x, g
+
+
+class CrossAttnUpBlock3D(_UpStage):
+    """reference unet_3d_blocks.py:622-765."""
+
+
+class UpBlock3D(_UpStage):
+    """reference unet_3d_blocks.py:768-842."""
+
+
+class UNetMidBlock3DCrossAttn(nn.Module):
+    """reference unet_3d_blocks.py:234-386."""
+
+    def __init__(self, channels, temb_channels, eps, groups, heads, head_dim, cross_attention_dim,
+                 output_scale_factor=1.0):
+        super().__init__()
+        self.has_cross_attention = True
+        self.gradient_checkpointing = False
+        self.resnets = nn.ModuleList([ResnetBlock2D(channels, channels, temb_channels, eps=eps, groups=groups,
+                                                    output_scale_factor=output_scale_factor) for _ in range(2)])
+        self.temp_convs = nn.ModuleList([TemporalConvLayer(channels, channels, dropout=0.1) for _ in range(2)])
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, head_dim, channels, cross_attention_dim, groups)])
+        self.temp_attentions = nn.ModuleList([TransformerTemporalModel(heads, head_dim, channels, groups)])
+
+    def tokens(self, x, g, temb_silu, text, text_len):
+        x = self.resnets[0].tokens(x, g, temb_silu)
+        x = self.temp_convs[0].tokens(x, g)             # unconditional in the reference (:353-354)
+        x = self.attentions[0].tokens(x, g, text, text_len)
+        if g.frames > 1:
+            x = self.temp_attentions[0].tokens(x, g)
+        x = self.resnets[1].tokens(x, g, temb_silu)
+        if g.frames > 1:
+            x = self.temp_convs[1].tokens(x, g)
+        return x
+
+
+_DOWN = {"CrossAttnDownBlock3D": CrossAttnDownBlock3D, "DownBlock3D": DownBlock3D}
+_UP = {"CrossAttnUpBlock3D": CrossAttnUpBlock3D, "UpBlock3D": UpBlock3D}
+
+
+class UNet3DConditionModel(nn.Module):
+    """Constructor arguments / defaults: reference unet_3d_condition_mask.py:87-110."""
+
+    config_name = "config.json"
+    _supports_gradient_checkpointing = True
+
+    def __init__(self, sample_size=None, in_channels=4, out_channels=4,
+                 down_block_types=("CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"),
+                 up_block_types=("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"),
+                 block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, downsample_padding=1,
+                 mid_block_scale_factor=1, act_fn="silu", norm_num_groups=32, norm_eps=1e-5,
+                 cross_attention_dim=1024, attention_head_dim=64, motion_mask=False, motion_strength=False):
+        super().__init__()
+        if len(down_block_types) != len(up_block_types):
+            raise ValueError(f"Must provide the same number of `down_block_types` as `up_block_types`. "
+                             f"`down_block_types`: {down_block_types}. `up_block_types`: {up_block_types}.")
+        if len(block_out_channels) != len(down_block_types):
+            raise ValueError(f"Must provide the same number of `block_out_channels` as `down_block_types`. "
+                             f"`block_out_channels`: {block_out_channels}. `down_block_types`: {down_block_types}.")
+        if not isinstance(attention_head_dim, int) and len(attention_head_dim) != len(down_block_types):
+            raise ValueError(f"Must provide the same number of `attention_head_dim` as `down_block_types`. "
+                             f"`attention_head_dim`: {attention_head_dim}. `down_block_types`: {down_block_types}.")
+        if act_fn not in ("silu", "swish"):
+            raise ValueError("only act_fn='silu' is implemented")
+        self.config = SimpleNamespace(
+            sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+            down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+            block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+            downsample_padding=downsample_padding, mid_block_scale_factor=mid_block_scale_factor, act_fn=act_fn,
+            norm_num_groups=norm_num_groups, norm_eps=norm_eps, cross_attention_dim=cross_attention_dim,
+            attention_head_dim=attention_head_dim, motion_mask=motion_mask, motion_strength=motion_strength)
+        self.motion_mask, self.motion_strength, self.sample_size = motion_mask, motion_strength, sample_size
+        self.gradient_checkpointing = False
+        ch0 = block_out_channels[0]
+        temb = ch0 * 4
+        n = len(block_out_channels)
+        hd = (attention_head_dim,) * n if isinstance(attention_head_dim, int) else tuple(attention_head_dim)
+        if any(d != 64 for d in hd):
+            raise ValueError("the MI355X attention kernel implements attention_head_dim == 64 (the v1.02 architecture)")
+
+        self.conv_in = Conv2d(in_channels, ch0, 3, padding=1)
+        self.conv_in2 = Conv2d(5, ch0, 3, padding=1)
+        self.time_embedding = TimestepEmbedding(ch0, temb, cond_proj_dim=ch0)
+        self.motion_embedding = nn.Sequential(nn.Linear(ch0, temb), nn.SiLU(), nn.Linear(temb, temb))  # unused by forward, kept for checkpoints
+        nn.init.zeros_(self.motion_embedding[-1].weight)
+        nn.init.zeros_(self.motion_embedding[-1].bias)
+        self.transformer_in = TransformerTemporalModel(8, hd[0], ch0, norm_num_groups)
+
+        self.down_blocks = nn.ModuleList()
+        out_c = ch0
+        for i, kind in enumerate(down_block_types):
+            if kind not in _DOWN:
+                raise ValueError(f"{kind} does not exist.")
+            in_c, out_c = out_c, block_out_channels[i]
+            io = [(in_c if j == 0 else out_c, out_c) for j in range(layers_per_block)]
+            attn = dict(heads=out_c // hd[i], head_dim=hd[i], cross_attention_dim=cross_attention_dim) \
+                if kind.startswith("CrossAttn") else {}
+            self.down_blocks.append(_DOWN[kind](io, temb, norm_eps, norm_num_groups,
+                                                down=downsample_padding if i < n - 1 else None, **attn))
+
+        cm = block_out_channels[-1]
+        self.mid_block = UNetMidBlock3DCrossAttn(cm, temb, norm_eps, norm_num_groups, cm // hd[-1], hd[-1],
+                                                 cross_attention_dim, mid_block_scale_factor)
+
+        self.up_blocks = nn.ModuleList()
+        rev, rhd = list(reversed(block_out_channels)), list(reversed(hd))
+        out_c = rev[0]
+        self.num_upsamplers = 0
+        for i, kind in enumerate(up_block_types):
+            if kind not in _UP:
+                raise ValueError(f"{kind} does not exist.")
+            prev_c, out_c = out_c, rev[i]
+            skip_c = rev[min(i + 1, n - 1)]
+            L = layers_per_block + 1
+            io = [((prev_c if j == 0 else out_c) + (skip_c if j == L - 1 else out_c), out_c) for j in range(L)]
+            up = i < n - 1
+            self.num_upsamplers += int(up)
+            attn = dict(heads=out_c // rhd[i], head_dim=rhd[i], cross_attention_dim=cross_attention_dim) \
+                if kind.startswith("CrossAttn") else {}
+            self.up_blocks.append(_UP[kind](io, temb, norm_eps, norm_num_groups, up=up, **attn))
+
+        self.conv_norm_out = GroupNorm(norm_num_groups, ch0, eps=norm_eps)
+        self.conv_act = nn.SiLU()
+        self.conv_out = Conv2d(ch0, out_channels, 3, padding=1)
+        self._graph = None
+
+    # ------------------------------------------------------------------ nn.Module / diffusers protocol
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def _apply(self, fn, *a, **k):
+        self._graph = None
+        return super()._apply(fn, *a, **k)
+
+    def enable_gradient_checkpointing(self):       # inference-only implementation: accepted, no effect
+        self.gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        self.gradient_checkpointing = False
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):   # flash attention is always on
+        return None
+
+    def set_attention_slice(self, slice_size):     # scores never leave the chip: slicing is moot
+        return None
+
+    @classmethod
+    def from_config(cls, config: dict, **overrides):
+        cfg = {k: v for k, v in dict(config).items() if not k.startswith("_")}
+        cfg.update(overrides)
+        import inspect
+        ok = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        return cls(**{k: v for k, v in cfg.items() if k in ok})
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **overrides):
+        """Load a diffusers-format directory (config.json + diffusion_pytorch_model.{safetensors,bin})."""
+        root = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(root, cls.config_name)) as f:
+            model = cls.from_config(json.load(f), **overrides)
+        st = os.path.join(root, "diffusion_pytorch_model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            state = load_file(st)
+        else:
+            state = torch.load(os.path.join(root, "diffusion_pytorch_model.bin"), map_location="cpu")
+        model.load_state_dict(state)
+        return model.to(torch_dtype) if torch_dtype is not None else model
+
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        cfg = dict(vars(self.config), _class_name="UNet3DConditionModel")
+        with open(os.path.join(path, self.config_name), "w") as f:
+            json.dump(cfg, f, indent=2)
+        from safetensors.torch import save_file
+        save_file({k: v.contiguous().cpu() for k, v in self.state_dict().items()},
+                  os.path.join(path, "diffusion_pytorch_model.safetensors"))
+
+    # ------------------------------------------------------------------ hot path
+    def _core(self, x8, t_sin, cond_sin, text_tokens, g: Grid, text_len: int, use_mask: bool, upsample_sizes):
+        """Everything between the boundary tensors: only libaa_mi355 launches (graph-capturable).
+        x8: [tokens, 8] input latents (+mask) zero-padded to 8 channels; returns [tokens, out_channels]."""
+        temb_silu = self.time_embedding.tokens(t_sin, cond_sin, final_silu=True)       # [clips, 4*ch0]
+        conv_in = self.conv_in2 if use_mask else self.conv_in
+        x = conv_in.tokens(x8, ops.conv3x3_geom(g.images, g.h, g.w))
+        if g.frames > 1:
+            x = self.transformer_in.tokens(x, g)
+        skips = [(x, g)]
+        for blk in self.down_blocks:
+            x, g, outs = blk.tokens(x, g, temb_silu, text_tokens, text_len)
+            skips += outs
+        x = self.mid_block.tokens(x, g, temb_silu, text_tokens, text_len)
+        for i, blk in enumerate(self.up_blocks):
+            x, g = blk.tokens(x, g, skips, temb_silu, text_tokens, text_len, upsample_size=upsample_sizes[i])
+        x = self.conv_norm_out.tokens(x, g.images, g.hw, silu=True)
+        return self.conv_out.tokens(x, ops.conv3x3_geom(g.images, g.h, g.w))
+
+    def forward(self, sample, timestep, encoder_hidden_states, condition_latent, mask, class_labels=None,
+                timestep_cond=None, attention_mask=None, cross_attention_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, motion=None,
+                return_dict=True, image_embeds=None):
+        """reference unet_3d_condition_mask.py:338-526.  `attention_mask`, `class_labels`,
+        `cross_attention_kwargs`, `image_embeds` are accepted and unused, as in the reference."""
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            raise NotImplementedError("ControlNet residual hooks are not part of the MI355X hot path")
+        if not sample.is_cuda and not _lib.host_pointers_ok():
+            raise RuntimeError("animate_anything_amd.UNet3DConditionModel runs on the GPU only (no CPU fallback)")
+        dt, dev = self.dtype, sample.device
+        sample = torch.cat([condition_latent.to(dt), sample.to(dt)], dim=2)            # :376
+        b, _, frames, h, w = sample.shape
+        up_factor = 2 ** self.num_upsamplers
+        forward_upsample = (h % up_factor != 0) or (w % up_factor != 0)               # :381
+
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], dtype=torch.float64 if isinstance(t, float) else torch.int64, device=dev)
+        elif t.dim() == 0:
+            t = t[None]
+        t = t.to(dev).expand(b)
+        ch0 = self.conv_in.out_channels
+        t_sin = timestep_sinusoid(t, ch0).to(dt)                                        # :408-413
+        cond_sin = None
+        if self.motion_strength and motion is not None:                                 # :414-416
+            m = torch.as_tensor(motion, device=dev)
+            cond_sin = timestep_sinusoid(m, ch0).to(dt).expand(b, ch0).contiguous()
+        elif timestep_cond is not None:
+            cond_sin = timestep_cond.to(dt).expand(b, ch0).contiguous()
+
+        use_mask = bool(self.motion_mask and mask is not None)
+        if use_mask:                                                                    # :424-428
+            mm = mask.to(dt).repeat(b // mask.shape[0], 1, frames, 1, 1)
+            sample = torch.cat([mm, sample], dim=1)
+        cin = sample.shape[1]
+        x8 = torch.zeros(b, frames, h, w, 8, dtype=dt, device=dev)
+        x8[..., :cin] = sample.permute(0, 2, 3, 4, 1)
+        x8 = x8.reshape(-1, 8)
+
+        text = encoder_hidden_states.to(dt)
+        text_len = text.shape[1]
+        text_tokens = text.reshape(-1, text.shape[-1]).contiguous()
+        g = Grid(b, frames, h, w)
+
+        # sizes the up path must hit when H or W is not a multiple of 2**num_upsamplers (:490-491)
+        sizes = [(h, w)]
+        for _ in range(self.num_upsamplers):
+            ph, pw = sizes[-1]
+            sizes.append(((ph - 1) // 2 + 1, (pw - 1) // 2 + 1))
+        upsample_sizes = [None] * len(self.up_blocks)
+        if forward_upsample:
+            for i in range(self.num_upsamplers):
+                upsample_sizes[i] = sizes[self.num_upsamplers - 1 - i]
+
+        y = self._run_core(x8, t_sin.contiguous(), cond_sin, text_tokens, g, text_len, use_mask, tuple(upsample_sizes))
+        y = y.reshape(b, frames, h, w, -1).permute(0, 4, 1, 2, 3)[:, :, 1:]            # :521-522
+        return UNet3DConditionOutput(sample=y) if return_dict else (y,)
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def enable_graph(self, enabled=True):
+        """Capture `_core` in a hipGraph on first use per input signature and replay it afterwards
+        (removes ~1k host launches per denoising step)."""
+        self._graph = {} if enabled else None
+
+    def _run_core(self, x8, t_sin, cond_sin, text_tokens, g, text_len, use_mask, upsample_sizes):
+        if self._graph is None:
+            return self._core(x8, t_sin, cond_sin, text_tokens, g, text_len, use_mask, upsample_sizes)
+        key = (tuple(x8.shape), tuple(text_tokens.shape), g, text_len, use_mask, upsample_sizes, cond_sin is None,
+               x8.dtype)
+        ent = self._graph.get(key)
+        if ent is None:
+            static = dict(x8=x8.clone(), t=t_sin.clone(), c=None if cond_sin is None else cond_sin.clone(),
+                          text=text_tokens.clone())
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                                   # warm-up outside capture (packs weights)
+                self._core(static["x8"], static["t"], static["c"], static["text"], g, text_len, use_mask, upsample_sizes)
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._core(static["x8"], static["t"], static["c"], static["text"], g, text_len, use_mask,
+                                 upsample_sizes)
+            ent = self._graph[key] = (graph, static, out)
+        graph, static, out = ent
+        static["x8"].copy_(x8)
+        static["t"].copy_(t_sin)
+        if cond_sin is not None:
+            static["c"].copy_(cond_sin)
+        static["text"].copy_(text_tokens)
+        graph.replay()
+        return out

@@ -1,8 +1,10 @@
-"""Kernel bodies run on the CPU SIMT emulator (tests/emu) against plain fp32 torch references.
+"""Per-kernel parity against plain fp32 torch references of the same op, on two backends:
 
-These tests exercise the SAME kernel sources and the SAME host-side packing/descriptor code as the
-GPU path; they validate index arithmetic, LDS staging and MFMA fragment bookkeeping (not timing and
-not the hardware itself -- the `-m gpu` tests do that)."""
+  emu  the kernel sources compiled for the host on the SIMT emulator (tests/emu) -- runs anywhere,
+       validates index arithmetic, LDS staging and MFMA fragment bookkeeping;
+  gpu  libaa_mi355.so on a real MI355X (`-m gpu`) -- validates the hardware path itself.
+
+Both go through the same C ABI and the same host-side packing / descriptor code (ops.py)."""
 import math
 
 import pytest
@@ -15,13 +17,29 @@ from animate_anything_amd._lib import AA_ACT_SILU
 DT = torch.float16
 
 
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def backend(request):
+    global DEV
+    if request.param == "emu":
+        DEV = "cpu"
+        request.getfixturevalue("emu")
+    else:
+        assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+        DEV = "cuda"
+    yield request.param
+    DEV = "cpu"
+
+
+DEV = "cpu"
+
+
 def rnd(*shape, scale=1.0, seed=0):
     g = torch.Generator().manual_seed(seed)
-    return (torch.randn(*shape, generator=g) * scale).to(DT)
+    return (torch.randn(*shape, generator=g) * scale).to(DT).to(DEV)
 
 
 def close(a, b, tol=2e-2):
-    a, b = a.float(), b.float()
+    a, b = a.float().cpu(), b.float().cpu()
     err = (a - b).abs().max().item()
     ref = b.abs().max().item() + 1e-6
     assert err <= tol * max(1.0, ref), f"max err {err} (ref max {ref})"
@@ -31,7 +49,7 @@ def nhwc(x):   # [N,C,H,W] -> tokens x C
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
 
 
-def test_linear_bias_silu_residual(emu):
+def test_linear_bias_silu_residual(backend):
     M, K, N = 200, 96, 80
     x, w, b, r = rnd(M, K, seed=1), rnd(N, K, scale=0.1, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
     pw = ops.pack_weight(w, b)
@@ -41,7 +59,7 @@ def test_linear_bias_silu_residual(emu):
     close(y, ref)
 
 
-def test_linear_bn64_fp32_out_scale_rowbias(emu):
+def test_linear_bn64_fp32_out_scale_rowbias(backend):
     M, K, N = 130, 64, 192
     x, w, b = rnd(M, K, seed=5), rnd(N, K, scale=0.1, seed=6), rnd(M, seed=7)
     pw = ops.pack_weight(w)
@@ -51,7 +69,7 @@ def test_linear_bn64_fp32_out_scale_rowbias(emu):
     close(y, 0.5 * (x.float() @ w.float().t() + b.float()[:, None]))
 
 
-def test_geglu(emu):
+def test_geglu(backend):
     M, K, D = 70, 64, 64
     x, w, b = rnd(M, K, seed=8), rnd(2 * D, K, scale=0.2, seed=9), rnd(2 * D, seed=10)
     y = ops.conv_gemm(x, ops.pack_weight(w, b, geglu=True), ops.linear_geom(M))
@@ -60,7 +78,7 @@ def test_geglu(emu):
 
 
 @pytest.mark.parametrize("stride,pad,up_to", [(1, 1, None), (2, 1, None), (2, 0, None), (1, 1, (10, 14)), (1, 1, (9, 13))])
-def test_conv3x3(emu, stride, pad, up_to):
+def test_conv3x3(backend, stride, pad, up_to):
     n, h, w, cin, cout = 2, 5, 7, 16, 72
     x, wt, b = rnd(n, cin, h, w, seed=11), rnd(cout, cin, 3, 3, scale=0.1, seed=12), rnd(cout, seed=13)
     g = ops.conv3x3_geom(n, h, w, stride=stride, pad=pad, up_to=up_to)
@@ -75,7 +93,7 @@ def test_conv3x3(emu, stride, pad, up_to):
     close(y, nhwc(ref))
 
 
-def test_conv3x3_concat_rowvec_cin5(emu):
+def test_conv3x3_concat_rowvec_cin5(backend):
     n, h, w, cout = 3, 4, 6, 64
     a, bsrc = rnd(n, 8, h, w, seed=14), rnd(n, 16, h, w, seed=15)
     wt, b, temb = rnd(cout, 24, 3, 3, scale=0.1, seed=16), rnd(cout, seed=17), rnd(n, cout, seed=18)
@@ -91,7 +109,7 @@ def test_conv3x3_concat_rowvec_cin5(emu):
     close(y5, nhwc(F.conv2d(x5.float(), w5.float(), b.float(), padding=1)))
 
 
-def test_temporal_conv(emu):
+def test_temporal_conv(backend):
     clips, frames, hh, ww, c = 2, 5, 2, 3, 16
     x = rnd(clips, c, frames, hh, ww, seed=21)
     wt, b = rnd(c, c, 3, 1, 1, scale=0.2, seed=22), rnd(c, seed=23)
@@ -103,7 +121,7 @@ def test_temporal_conv(emu):
 
 
 @pytest.mark.parametrize("c0,c1,groups,frames", [(64, 0, 32, 1), (40, 24, 32, 1), (80, 0, 8, 3), (2560, 0, 32, 1)])
-def test_groupnorm(emu, c0, c1, groups, frames):
+def test_groupnorm(backend, c0, c1, groups, frames):
     n, hw = 3 * frames, 37 if c0 < 1000 else 3
     C = c0 + c1
     x = rnd(n, C, hw, 1, seed=25) * 2 + 0.5
@@ -118,7 +136,7 @@ def test_groupnorm(emu, c0, c1, groups, frames):
 
 
 @pytest.mark.parametrize("C", [64, 320, 1280])
-def test_layernorm(emu, C):
+def test_layernorm(backend, C):
     x, g, b = rnd(10, C, seed=28) * 3 + 1, rnd(C, seed=29), rnd(C, seed=30)
     close(ops.layernorm(x, g, b, 1e-5), F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5))
 
@@ -128,7 +146,7 @@ def sdpa(q, k, v):
     return s.softmax(-1) @ v.float()
 
 
-def test_attention_spatial(emu):
+def test_attention_spatial(backend):
     n, heads, L = 2, 2, 100
     C = heads * 64
     qkv = rnd(n * L, 3 * C, seed=31)
@@ -138,7 +156,7 @@ def test_attention_spatial(emu):
     close(o, ref, tol=1e-2)
 
 
-def test_attention_cross_text(emu):
+def test_attention_cross_text(backend):
     clips, frames, heads, L, Lt = 2, 2, 1, 40, 77
     C = heads * 64
     q = rnd(clips * frames * L, C, seed=32)
@@ -150,7 +168,7 @@ def test_attention_cross_text(emu):
     close(o, ref, tol=1e-2)
 
 
-def test_attention_temporal(emu):
+def test_attention_temporal(backend):
     clips, frames, hw, heads = 2, 5, 6, 2
     C = heads * 64
     qkv = rnd(clips * frames * hw, 3 * C, seed=34)
@@ -161,14 +179,14 @@ def test_attention_temporal(emu):
     close(o, ref, tol=1e-2)
 
 
-def test_softmax_rows_and_dpm_step(emu):
+def test_softmax_rows_and_dpm_step(backend):
     g = torch.Generator().manual_seed(35)
-    s = torch.randn(5, 300, generator=g) * 4
+    s = (torch.randn(5, 300, generator=g) * 4).to(DEV)
     close(ops.softmax_rows(s, DT), s.softmax(-1), tol=2e-3)
     n = 1000
     eu, et = rnd(n, seed=36), rnd(n, seed=37)
-    x, x0p = torch.randn(n, generator=g), torch.randn(n, generator=g)
-    lp = torch.empty(n, dtype=DT)
+    x, x0p = torch.randn(n, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    lp = torch.empty(n, dtype=DT, device=DEV)
     xr, x0r = x.clone(), x0p.clone()
     ops.cfg_dpm_step(eu, et, x, x0p, lp, 9.0, 0.7, 0.71, 0.9, -0.2, -0.05)
     eps = eu.float() + 9.0 * (et.float() - eu.float())

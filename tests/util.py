@@ -1,0 +1,38 @@
+"""Shared helpers for the parity tests (seeded weights / inputs of SURVEY.md section 8d)."""
+import torch
+
+TINY_UNET = dict(block_out_channels=(64, 128), down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+                 up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"), layers_per_block=1, cross_attention_dim=64,
+                 motion_mask=True, motion_strength=True)
+SMALL_UNET = dict(block_out_channels=(64, 128, 256, 256), cross_attention_dim=128, motion_mask=True,
+                  motion_strength=True)
+TINY_VAE = dict(block_out_channels=(32, 64), layers_per_block=1)
+SMALL_VAE = dict(block_out_channels=(32, 64, 128, 128))
+
+
+def seeded_state(module, seed=0, rezero_std=0.02):
+    """PyTorch default inits under `seed`; parameters the architecture zero-initialises
+    (TemporalConvLayer.conv4, motion_embedding[-1]) are re-drawn N(0, 0.02^2) so no path is vacuous
+    (SURVEY.md section 0 item 4)."""
+    g = torch.Generator().manual_seed(seed + 1)
+    state = {}
+    for k, v in module.state_dict().items():
+        v = v.clone().float()
+        if v.abs().max() == 0:
+            v = torch.randn(v.shape, generator=g) * rezero_std
+        state[k] = v
+    return state
+
+
+def unet_inputs(b=2, frames=2, h=6, w=6, text_len=77, text_dim=64, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    mask = torch.zeros(1, 1, 1, h, w)
+    mask[..., h // 4: h - h // 4, w // 4: w - w // 4] = 1
+    return dict(sample=r(b, 4, frames, h, w), cond=r(b, 4, 1, h, w), mask=mask, text=r(b, text_len, text_dim),
+                motion=torch.tensor([3.0]), t=501)
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-6)).item()
