@@ -83,7 +83,7 @@ def bind(path: str) -> C.CDLL:
     lib.aa_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                  C.c_float, C.c_int32, C.c_void_p]
     lib.aa_attention.argtypes = [C.POINTER(AaAttention), C.c_void_p]
-    lib.aa_softmax_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+    lib.aa_softmax_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.aa_cfg_dpm_step.argtypes = [C.POINTER(AaDpmStep), C.c_void_p]
     for s in SYMBOLS[2:]:
         if s != "aa_groupnorm_workspace":

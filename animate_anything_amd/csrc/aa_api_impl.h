@@ -149,12 +149,12 @@ int aa_attention(const AaAttention* d, void* stream) {
     return fail(AA_E_DTYPE, "attention: unsupported dtype %d", d->dtype);
 }
 
-int aa_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int32_t dtype, void* stream) {
+int aa_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int32_t x_ld, int32_t y_ld, int32_t dtype, void* stream) {
     using namespace aa;
-    if (rows <= 0 || cols <= 0) return fail(AA_E_SHAPE, "softmax_rows: bad shape");
+    if (rows <= 0 || cols <= 0 || x_ld < cols || y_ld < cols) return fail(AA_E_SHAPE, "softmax_rows: bad shape");
     const dim3 grid((unsigned)rows), block(256);
-    if (dtype == AA_F16) AA_LAUNCH((softmax_rows_kernel<f16_t>), grid, block, 64, stream, x, (f16_t*)y, cols);
-    else if (dtype == AA_BF16) AA_LAUNCH((softmax_rows_kernel<bf16_t>), grid, block, 64, stream, x, (bf16_t*)y, cols);
+    if (dtype == AA_F16) AA_LAUNCH((softmax_rows_kernel<f16_t>), grid, block, 64, stream, x, (f16_t*)y, cols, x_ld, y_ld);
+    else if (dtype == AA_BF16) AA_LAUNCH((softmax_rows_kernel<bf16_t>), grid, block, 64, stream, x, (bf16_t*)y, cols, x_ld, y_ld);
     else return fail(AA_E_DTYPE, "softmax_rows: unsupported dtype %d", dtype);
     return finish("softmax_rows");
 }

@@ -194,11 +194,11 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* x, const T* gam
 
 // ---- row softmax of fp32 scores (VAE single-head attention), one workgroup per row.
 template <typename T>
-__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* x, T* y, int cols) {
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* x, T* y, int cols, int x_ld, int y_ld) {
     float* s_red = reinterpret_cast<float*>(dyn_smem());   // [8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* xr = x + (int64_t)blockIdx.x * cols;
-    T* yr = y + (int64_t)blockIdx.x * cols;
+    const float* xr = x + (int64_t)blockIdx.x * x_ld;
+    T* yr = y + (int64_t)blockIdx.x * y_ld;
     float mx = -3.0e38f;
     for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, xr[c]);
     mx = wave_max(mx);

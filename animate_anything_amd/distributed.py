@@ -1,0 +1,60 @@
+"""Batch-of-clips sharding across the GPUs of one node.
+
+The reference's inference is single-process (train.py:825-857).  Clips are independent units - each
+denoising loop only touches its own latents/prompt/mask (models/pipeline.py:163-198) - so the N-GPU
+path is: one process per GPU, rank r takes clips r, r+W, ..., weights replicated, NO collective in the
+data path, and ONE all-gather of the final latents (0.5 MB per clip at 16x64x64 fp16) over RCCL/xGMI.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*).
+    backend None -> "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo".  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    cuda = torch.cuda.is_available()
+    device = torch.device("cuda", local) if cuda else torch.device("cpu")
+    if cuda:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend or ("nccl" if cuda else "gloo"))
+    return rank, world, device
+
+
+def clip_indices(num_clips: int, rank: int, world: int) -> List[int]:
+    """Round-robin ownership: rank r denoises clips r, r+world, ..."""
+    return list(range(rank, num_clips, world))
+
+
+def clip_seed(base_seed: int, clip_index: int) -> int:
+    """Per-clip seed so results do not depend on the number of ranks."""
+    return base_seed + clip_index
+
+
+def gather_clips(local: torch.Tensor, num_clips: int, rank: int, world: int) -> torch.Tensor:
+    """All-gather per-rank results [n_local, ...] into [num_clips, ...] in clip order on every rank.
+    One collective; ranks with fewer clips pad to the common count."""
+    if world == 1:
+        return local
+    per = (num_clips + world - 1) // world
+    shape = (per,) + tuple(local.shape[1:])
+    padded = torch.zeros(shape, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    out = torch.empty((world,) + shape, dtype=local.dtype, device=local.device)
+    if dist.get_backend() == "gloo":
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded)
+        out = torch.stack(parts)
+    else:
+        dist.all_gather_into_tensor(out, padded)
+    # out[r, j] is clip r + j*world
+    order = out.transpose(0, 1).reshape((per * world,) + tuple(local.shape[1:]))
+    return order[:num_clips].contiguous()

@@ -101,9 +101,9 @@ class Conv3d(_Packed, nn.Conv3d):
 
 
 class GroupNorm(nn.GroupNorm):
-    def tokens(self, x, n_stat_groups, tokens_per_group, silu=False, x1=None):
+    def tokens(self, x, n_stat_groups, tokens_per_group, silu=False, x1=None, out=None):
         return ops.groupnorm(x, self.weight, self.bias, n_stat_groups, tokens_per_group, self.num_groups,
-                             self.eps, silu, x1=x1)
+                             self.eps, silu, x1=x1, out=out)
 
     def forward(self, x):
         _no_eager("GroupNorm")

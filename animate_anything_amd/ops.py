@@ -194,12 +194,12 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
 # ------------------------------------------------------------------------------------- norms
 def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_groups_img: int,
               tokens_per_group: int, num_groups: int = 32, eps: float = 1e-5, silu: bool = False,
-              x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+              x1: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.get()
-    _check(x0, x1, gamma, beta)
+    _check(x0, x1, gamma, beta, out)
     c0 = x0.shape[-1]
     c1 = 0 if x1 is None else x1.shape[-1]
-    y = torch.empty(n_groups_img * tokens_per_group, c0 + c1, dtype=x0.dtype, device=x0.device)
+    y = torch.empty(n_groups_img * tokens_per_group, c0 + c1, dtype=x0.dtype, device=x0.device) if out is None else out
     d = AaGroupNorm()
     d.x0, d.x1, d.gamma, d.beta, d.y = _ptr(x0), _ptr(x1), _ptr(gamma), _ptr(beta), _ptr(y)
     d.c0, d.c1 = c0, c1
@@ -248,12 +248,15 @@ def attention(q: torch.Tensor, q_col0: int, k: torch.Tensor, k_col0: int, v: tor
     return out
 
 
-def softmax_rows(x: torch.Tensor, dtype) -> torch.Tensor:
+def softmax_rows(x: torch.Tensor, dtype, cols: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Row softmax of fp32 scores over the first `cols` columns; `out` may be wider (its padding is
+    left untouched)."""
     lib = _lib.get()
-    _check(x)
+    _check(x, out)
     assert x.dtype == torch.float32
-    y = torch.empty(x.shape, dtype=dtype, device=x.device)
-    _run(lib.aa_softmax_rows, _ptr(x), _ptr(y), x.shape[0], x.shape[1], _DT[dtype], _stream(x))
+    cols = x.shape[1] if cols is None else cols
+    y = torch.empty(x.shape, dtype=dtype, device=x.device) if out is None else out
+    _run(lib.aa_softmax_rows, _ptr(x), _ptr(y), x.shape[0], cols, x.stride(0), y.stride(0), _DT[y.dtype], _stream(x))
     return y
 
 

@@ -146,8 +146,10 @@ int aa_attention(const AaAttention* d, void* stream);
 
 /* aa_softmax_rows: y[r, :] = softmax(x[r, :]) for fp32 scores (VAE mid-block single-head
  * attention, head_dim 512, where scores are materialised: diffusers Attention with
- * upcast_softmax). x fp32 [rows][cols], y storage dtype [rows][cols]. */
-int aa_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int32_t dtype, void* stream);
+ * upcast_softmax). x fp32 [rows][x_ld], y storage dtype [rows][y_ld]; only the first `cols` columns
+ * of each row are read / written. */
+int aa_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int32_t x_ld, int32_t y_ld,
+                    int32_t dtype, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * aa_cfg_dpm_step: fused classifier-free guidance + DPM-Solver++(2M) update of one denoising
