@@ -1,0 +1,102 @@
+"""The oracle against its committed golden vectors (tests/golden) and the structural known-answer
+properties that follow from the reference text alone."""
+import os
+
+import torch
+
+import oracle
+from util import TINY_UNET, TINY_VAE, seeded_state, unet_inputs
+
+GOLD = torch.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.pt"))
+
+
+def _unet(seed_state=True, **over):
+    torch.manual_seed(0)
+    net = oracle.UNet3DConditionModel(**{**TINY_UNET, **over}).eval()
+    if seed_state:
+        net.load_state_dict(seeded_state(net))
+    return net
+
+
+def test_unet_matches_golden():
+    net = _unet()
+    for name, (h, w) in {"unet_6x6": (6, 6), "unet_5x7": (5, 7)}.items():
+        i = unet_inputs(h=h, w=w, text_len=9)
+        with torch.no_grad():
+            y = net(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
+        assert (y - GOLD[name].float()).abs().max() < 2e-3
+
+
+def test_vae_and_scheduler_match_golden():
+    torch.manual_seed(0)
+    vae = oracle.AutoencoderKL(**TINY_VAE).eval()
+    vae.load_state_dict(seeded_state(vae))
+    x = torch.rand(2, 3, 12, 10, generator=torch.Generator().manual_seed(7)) * 2 - 1
+    with torch.no_grad():
+        z = vae.encode(x).latent_dist.mode()
+        img = vae.decode(z).sample
+    assert (z - GOLD["vae_latent"].float()).abs().max() < 2e-3
+    assert (img - GOLD["vae_image"].float()).abs().max() < 2e-3
+    s = oracle.DPMSolverMultistepScheduler()
+    s.set_timesteps(25)
+    assert s.timesteps.tolist() == GOLD["dpm_timesteps_25"].tolist()
+    assert s.timesteps[0] == 951 and s.timesteps[-1] == 39        # leading spacing, steps_offset 1
+    assert torch.allclose(torch.tensor(s.sigmas, dtype=torch.float32), GOLD["dpm_sigmas_25"])
+
+
+def test_state_dict_keys_follow_diffusers_layout():
+    keys = set(_unet(seed_state=False).state_dict().keys())
+    for k in ("conv_in.weight", "conv_in2.bias", "time_embedding.linear_1.weight", "time_embedding.cond_proj.weight",
+              "motion_embedding.2.bias", "transformer_in.transformer_blocks.0.attn2.to_out.0.bias",
+              "down_blocks.0.temp_convs.0.conv1.2.weight", "down_blocks.0.temp_convs.0.conv4.3.bias",
+              "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.weight",
+              "down_blocks.0.temp_attentions.0.proj_out.bias", "down_blocks.0.downsamplers.0.conv.weight",
+              "mid_block.resnets.1.time_emb_proj.weight", "up_blocks.0.upsamplers.0.conv.bias",
+              "up_blocks.1.resnets.0.conv_shortcut.weight", "conv_norm_out.weight", "conv_out.bias"):
+        assert k in keys, k
+    assert "time_embedding.cond_proj.bias" not in keys
+    assert "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.bias" not in keys
+    full = oracle.UNet3DConditionModel.__init__.__defaults__
+    assert (320, 640, 1280, 1280) in full and 1024 in full and 64 in full       # v1.02 architecture defaults
+
+
+def test_zero_initialised_temporal_conv_is_identity_and_frame0_dropped():
+    layer = oracle.TemporalConvLayer(64)
+    x = torch.randn(6, 64, 3, 3)
+    assert torch.equal(layer(x, num_frames=3), x)
+    net = _unet()
+    i = unet_inputs(frames=4, h=6, w=6, text_len=9)
+    with torch.no_grad():
+        y = net(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
+    assert y.shape == i["sample"].shape                            # condition frame prepended and dropped
+
+
+def test_motion_and_mask_paths_are_live():
+    net = _unet()
+    i = unet_inputs(h=6, w=6, text_len=9)
+    with torch.no_grad():
+        base = net(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
+        m2 = net(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=torch.tensor([8.0])).sample
+        k2 = net(i["sample"], i["t"], i["text"], i["cond"], 1 - i["mask"], motion=i["motion"]).sample
+        nomask = net(i["sample"], i["t"], i["text"], i["cond"], None, motion=i["motion"]).sample
+    assert (base - m2).abs().max() > 1e-4 and (base - k2).abs().max() > 1e-4 and (base - nomask).abs().max() > 1e-4
+
+
+def test_guidance_le_one_does_not_double_batch():
+    seen = []
+
+    class U:
+        dtype = torch.float32
+
+        def __call__(self, x, t, **kw):
+            seen.append((x.shape[0], kw["encoder_hidden_states"].shape[0], kw["condition_latent"].shape[0]))
+            from types import SimpleNamespace
+            return SimpleNamespace(sample=torch.zeros_like(x))
+
+    lat, cond = torch.randn(1, 4, 2, 4, 4), torch.randn(1, 4, 1, 4, 4)
+    for g, want in ((1.0, (1, 1, 1)), (9.0, (2, 2, 2))):
+        seen.clear()
+        oracle.LatentToVideoPipeline(None, U(), oracle.DPMSolverMultistepScheduler())(
+            latents=lat, prompt_embeds=torch.zeros(1, 7, 16), negative_prompt_embeds=torch.zeros(1, 7, 16),
+            condition_latent=cond, mask=None, motion=None, num_inference_steps=2, guidance_scale=g, return_dict=False)
+        assert seen and all(s == want for s in seen)
