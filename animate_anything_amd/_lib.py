@@ -8,6 +8,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (must precede the dlopen below: libaa_mi355.so has to bind to the HIP runtime
+#                           torch already loaded, otherwise two runtimes end up in one process)
+
 AA_F16, AA_BF16, AA_F32 = 0, 1, 2
 AA_ACT_NONE, AA_ACT_SILU = 0, 1
 

@@ -50,7 +50,9 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
 template <typename T>
 static int groupnorm_t(const AaGroupNorm& d, float* ws, int chunks, int apply_chunks, void* stream) {
     const int C = d.c0 + d.c1;
-    AA_LAUNCH((groupnorm_stats_kernel<T>), dim3(chunks, d.n_groups_img), dim3(GN_THREADS), (size_t)C * 8, stream, d, ws, chunks);
+    const int S = C / 8;
+    const int rpp = S <= GN_THREADS ? GN_THREADS / S : 1;
+    AA_LAUNCH((groupnorm_stats_kernel<T>), dim3(chunks, d.n_groups_img), dim3(GN_THREADS), (size_t)C * 8 * (1 + rpp), stream, d, ws, chunks);
     const size_t lds = ((size_t)2 * C + 2 * (GN_THREADS + d.num_groups)) * 4;
     AA_LAUNCH((groupnorm_apply_kernel<T>), dim3(apply_chunks, d.n_groups_img), dim3(GN_THREADS), lds, stream, d, (const float*)ws, chunks, apply_chunks);
     return finish("groupnorm");

@@ -45,10 +45,10 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_stats_kernel(const AaGro
     const T* x0 = reinterpret_cast<const T*>(p.x0);
     const T* x1 = reinterpret_cast<const T*>(p.x1);
 
-    for (int c = tid; c < C; c += GN_THREADS) { s_sum[c] = 0.0f; s_sq[c] = 0.0f; }
-    __syncthreads();
-
+    // Per-thread channel sums are parked in LDS as [row lane][channel] and folded in a fixed order
+    // (no floating-point atomics: results are bit-reproducible run to run).
     const int rows_per_pass = S <= GN_THREADS ? GN_THREADS / S : 1;
+    float* s_part = s_sq + C;                                   // [rows_per_pass][2][C]
     for (int s0 = 0; s0 < S; s0 += GN_THREADS) {
         const int lin = tid;
         const int slot = s0 + (S <= GN_THREADS ? lin % S : lin);
@@ -64,8 +64,17 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_stats_kernel(const AaGro
                 for (int e = 0; e < 8; ++e) { const float f = (float)v.e[e]; a[e] += f; b[e] += f * f; }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { atomicAdd(&s_sum[slot * 8 + e], a[e]); atomicAdd(&s_sq[slot * 8 + e], b[e]); }
+            for (int e = 0; e < 8; ++e) {
+                s_part[(roff * 2 + 0) * C + slot * 8 + e] = a[e];
+                s_part[(roff * 2 + 1) * C + slot * 8 + e] = b[e];
+            }
         }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += GN_THREADS) {
+        float a = 0.0f, b = 0.0f;
+        for (int rr = 0; rr < rows_per_pass; ++rr) { a += s_part[(rr * 2 + 0) * C + c]; b += s_part[(rr * 2 + 1) * C + c]; }
+        s_sum[c] = a; s_sq[c] = b;
     }
     __syncthreads();
     if (tid < p.num_groups) {

@@ -65,11 +65,12 @@ def synthetic_inputs(frames, lat, dtype, device, seed=1234):
     return {k: v.to(device=device, dtype=dtype if k != "latents" else torch.float32) for k, v in d.items()}
 
 
-def cpu_baseline(frames_sample, lat):
-    """Oracle UNet forward (fp32, all host cores) on a bounded sample: the CFG batch of 2 at full 64x64
-    latent resolution but `frames_sample`+1 frames instead of 17; scaled by the token ratio."""
+def cpu_baseline(frames_sample, lat_full, lat=32):
+    """Oracle UNet forward (fp32 CPU, `cores` threads) on a bounded sample of the workload: the CFG batch
+    of 2, `frames_sample`+1 of the 17 frames, at `lat`x`lat` instead of 64x64 latents; steps/s scaled by
+    the token ratio (all per-token costs are linear except spatial attention, which this under-counts)."""
     import oracle
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     net = oracle.UNet3DConditionModel(motion_mask=True, motion_strength=True).eval()
@@ -81,10 +82,10 @@ def cpu_baseline(frames_sample, lat):
     with torch.no_grad():
         net(x, 500, txt, c, m, motion=torch.tensor([3.0]))
     dt = time.perf_counter() - t0
-    scale = 17.0 / (frames_sample + 1)
+    scale = 17.0 / (frames_sample + 1) * (lat_full / lat) ** 2
     return dict(value=1.0 / (dt * scale), unit="steps/s", cores=cores, kind="port",
-                sample=f"oracle UNet3D forward fp32, CFG batch 2, {frames_sample}+1 of 16+1 frames at {lat}x{lat} latents, "
-                       f"{dt:.1f} s measured, scaled x{scale:.2f} by token count")
+                sample=f"oracle UNet3D forward fp32 on {cores} threads, CFG batch 2, {frames_sample}+1 of 16+1 frames at "
+                       f"{lat}x{lat} (of {lat_full}x{lat_full}) latents, {dt:.1f} s measured, scaled x{scale:.1f} by token count")
 
 
 def main():
