@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include "aa_mi355.h"
 #include "kernels/conv_gemm.h"
+#include "kernels/conv_gemm_dma.h"
 #include "kernels/norm.h"
 #include "kernels/attention.h"
 
@@ -42,6 +43,15 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
     const int tiles_m = (M + CG_BM - 1) / CG_BM;
     const int tiles_n = d.n_pad / bn;
     const dim3 grid(tiles_m * tiles_n), block(CG_THREADS);
+    // LDS-DMA fast path: K tiles never straddle a filter tap / concat source, output rows are 16-byte chunks
+    const int n_cols = d.geglu ? d.n_out / 2 : d.n_out;
+    const bool dma = (d.c0 + d.c1) % 64 == 0 && d.c0 % 64 == 0 && d.out_dtype == d.dtype && n_cols % 8 == 0 &&
+                     d.ldo % 8 == 0 && aligned16(d.out) && (!d.residual || (d.ldr % 8 == 0 && aligned16(d.residual)));
+    if (dma) {
+        if (bn128) AA_LAUNCH((conv_gemm_dma_kernel<T, 128>), grid, block, cgd_lds_bytes(128), stream, d, M, tiles_n);
+        else       AA_LAUNCH((conv_gemm_dma_kernel<T, 64>), grid, block, cgd_lds_bytes(64), stream, d, M, tiles_n);
+        return finish("conv_gemm");
+    }
     if (bn128) AA_LAUNCH((conv_gemm_kernel<T, 128>), grid, block, cg_lds_bytes(128), stream, d, M, tiles_n);
     else       AA_LAUNCH((conv_gemm_kernel<T, 64>), grid, block, cg_lds_bytes(64), stream, d, M, tiles_n);
     return finish("conv_gemm");

@@ -1,0 +1,213 @@
+// Implicit-GEMM convolution / linear kernel, LDS-DMA edition (fast path of aa_conv_gemm).
+//
+// Same tiling as conv_gemm.h (128 x BN tile, K step 64, 2x2 waves, v_mfma_f32_32x32x16) but both operand
+// tiles travel HBM -> LDS with `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass):
+//  * every wave instruction deposits 64 lanes x 16 B = 8 tile rows x 128 B, lane-linear; the im2col gather,
+//    the conv halo and the M / K tails are expressed in the per-lane SOURCE address (halo lanes read a
+//    16-byte zero page);
+//  * bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle applied on the source
+//    side (lane l of row r fetches k-slot (l&7) ^ ((r>>1)&7)) and undone on the read side;
+//  * requires the K tile to sit inside one filter tap and one concat source ((c0+c1) % 64 == 0 and
+//    c0 % 64 == 0): tap / source / channel base are then wave-uniform scalars and the per-row pixel offsets
+//    are recomputed only when the tap changes;
+//  * two LDS buffers, tile t+1 in flight while tile t is multiplied, one barrier per K step;
+//  * epilogue: bias / time-embedding row vector / SiLU / GEGLU in registers, tile parked in LDS as storage
+//    dtype, read back row-major so residual loads and output stores are full 16-byte, row-contiguous.
+#pragma once
+#include "dev.h"
+#include "aa_mi355.h"
+#include "conv_gemm.h"
+
+namespace aa {
+
+__host__ __device__ inline int cgd_lds_bytes(int bn) { return 2 * (CG_BM + bn) * CG_BK * 2; }
+
+template <typename T, int BN>
+__global__ void __launch_bounds__(CG_THREADS) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n) {
+    constexpr int NT = BN / 64;
+    constexpr int BJ = BN / 32;          // weight-row DMA instructions per wave
+    constexpr int ROWB = CG_BK * 2;      // bytes per LDS tile row (128)
+    char* smem = dyn_smem();
+    char* sA = smem;                                  // [2][128][128 B]
+    char* sB = smem + 2 * CG_BM * ROWB;               // [2][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile_m = logical / tiles_n;
+    const int tile_n = logical - tile_m * tiles_n;
+
+    const int ctot = p.c0 + p.c1;
+    const int nk = p.k_pad / CG_BK;
+    const bool resize = (p.h_virt != p.h_in) || (p.w_virt != p.w_in);
+
+    // ---- DMA geometry: this lane feeds LDS rows (wave*32 + j*8 + lane/8), 16-byte position lane%8 ----
+    const int lrow = lane >> 3, lpos = lane & 7;
+    int row_img[4], row_iy[4], row_ix[4], kslot[4];
+    bool row_ok[4];
+    int64_t pix[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = wave * 32 + j * 8 + lrow;
+        const int m = tile_m * CG_BM + rr;
+        row_ok[j] = m < M;
+        const int mm = row_ok[j] ? m : 0;
+        const int x = mm % p.w_out;
+        const int t = mm / p.w_out;
+        const int y = t % p.h_out;
+        row_img[j] = t / p.h_out;
+        row_iy[j] = y * p.stride - p.pad_h;
+        row_ix[j] = x * p.stride - p.pad_w;
+        kslot[j] = lpos ^ ((rr >> 1) & 7);
+        pix[j] = -1;
+    }
+    const T* wsrc[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int rr = wave * (BN / 4) + j * 8 + lrow;
+        wsrc[j] = reinterpret_cast<const T*>(p.w) + (int64_t)(tile_n * BN + rr) * p.k_pad + (lpos ^ ((rr >> 1) & 7)) * 8;
+    }
+    const T* zero = reinterpret_cast<const T*>(zero_page());
+
+    int cur_tap = -1;
+    auto issue = [&](int kt, int buf) {
+        const int k0 = kt * CG_BK;
+        const int tap = k0 / ctot;                     // wave-uniform
+        const int cb = k0 - tap * ctot;
+        if (tap != cur_tap) {
+            cur_tap = tap;
+            const int dy = tap / p.kw, dx = tap - dy * p.kw;
+            const bool tap_ok = tap < p.kh * p.kw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = row_iy[j] + dy, ix = row_ix[j] + dx;
+                const bool ok = tap_ok && row_ok[j] && (unsigned)iy < (unsigned)p.h_virt && (unsigned)ix < (unsigned)p.w_virt;
+                int sy = iy, sx = ix;
+                if (resize) { sy = (iy * p.h_in) / p.h_virt; sx = (ix * p.w_in) / p.w_virt; }
+                pix[j] = ok ? ((int64_t)row_img[j] * p.h_in + sy) * p.w_in + sx : -1;
+            }
+        }
+        const T* src; int cs, cc;
+        if (cb < p.c0) { src = reinterpret_cast<const T*>(p.a0); cs = p.c0; cc = cb; }
+        else           { src = reinterpret_cast<const T*>(p.a1); cs = p.c1; cc = cb - p.c0; }
+        char* a = sA + buf * CG_BM * ROWB + wave * 32 * ROWB;
+        char* b = sB + buf * BN * ROWB + wave * (BN / 4) * ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T* g = pix[j] >= 0 ? src + pix[j] * cs + cc + kslot[j] * 8 : zero;
+            async_copy16(g, a + j * 8 * ROWB);
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) async_copy16(wsrc[j] + (int64_t)kt * CG_BK, b + j * 8 * ROWB);
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // fragment read offsets (bytes): row = base + (lane&31), k-slot ks*2 + (lane>>5), un-swizzled per row
+    const int frow = lane & 31, fh = lane >> 5;
+    int a_off[2], b_off[NT], a_swz[2], b_swz[NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int rr = wm * 64 + i * 32 + frow; a_off[i] = rr * ROWB; a_swz[i] = (rr >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { const int rr = wn * (BN / 2) + j * 32 + frow; b_off[j] = rr * ROWB; b_swz[j] = (rr >> 1) & 7; }
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                 // tile kt has landed (DMA drained before the barrier), buffer (kt+1)&1 is free
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* a = sA + (kt & 1) * CG_BM * ROWB;
+        const char* b = sB + (kt & 1) * BN * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < CG_BK / 16; ++ks) {
+            u32x4 fa[2], fb[NT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const u32x4*>(a + a_off[i] + (((ks * 2 + fh) ^ a_swz[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b + b_off[j] + (((ks * 2 + fh) ^ b_swz[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_32x32x16(T(), fa[i], fb[j], acc[i][j]);
+        }
+    }
+    __syncthreads();                     // operand buffers are dead: reuse them for the output tile
+
+    // ---- epilogue part 1 (registers): bias, row vector, activation, GEGLU -> storage dtype tile in LDS ----
+    constexpr int LDE = BN + 8;          // padded row length (elements) of the staged output tile
+    T* sE = reinterpret_cast<T*>(smem);
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    const T* rowvec = reinterpret_cast<const T*>(p.rowvec);
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    const int out_cols = p.geglu ? BN / 2 : BN;          // tile width in output columns
+    if (p.geglu) {
+        if constexpr (NT == 2) {
+            const int npk = tile_n * BN + wn * 64;
+            const float bv = bias ? (float)bias[npk + col_l] : 0.0f;
+            const float bg = bias ? (float)bias[npk + 32 + col_l] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
+                    sE[rr * LDE + wn * 32 + col_l] = (T)((acc[i][0][e] + bv) * gelu_erf_f(acc[i][1][e] + bg));
+                }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int nl = wn * (BN / 2) + j * 32 + col_l;
+            const int n = tile_n * BN + nl;
+            const bool c_ok = n < p.n_out;
+            const float bcol = (bias && c_ok && !p.bias_per_row) ? (float)bias[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
+                    const int m = tile_m * CG_BM + rr;
+                    float v = acc[i][j][e] + bcol;
+                    if (c_ok && m < M) {
+                        if (p.bias_per_row && bias) v += (float)bias[m];
+                        if (rowvec) v += (float)rowvec[(int64_t)(m / p.rowvec_div) * p.n_out + n];
+                    }
+                    if (p.act == AA_ACT_SILU) v = silu_f(v);
+                    sE[rr * LDE + nl] = (T)v;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue part 2 (row-major, 16 B per lane): + residual, * scale, store ----
+    const T* resid = reinterpret_cast<const T*>(p.residual);
+    T* out = reinterpret_cast<T*>(p.out);
+    const int n_cols = p.geglu ? (p.n_out >> 1) : p.n_out;
+    const int chunks_per_row = out_cols >> 3;
+    const int col0 = tile_n * out_cols;
+    for (int c = tid; c < CG_BM * chunks_per_row; c += CG_THREADS) {
+        const int rr = c / chunks_per_row, ch = c - rr * chunks_per_row;
+        const int m = tile_m * CG_BM + rr, n = col0 + ch * 8;
+        if (m >= M || n >= n_cols) continue;
+        Pack8<T> v; v.raw = *reinterpret_cast<const u32x4*>(sE + rr * LDE + ch * 8);
+        if (resid || p.out_scale != 1.0f) {
+            Pack8<T> rs; rs.raw = u32x4{0u, 0u, 0u, 0u};
+            if (resid) rs.raw = *reinterpret_cast<const u32x4*>(resid + (int64_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.e[e] = (T)(((float)v.e[e] + (float)rs.e[e]) * p.out_scale);
+        }
+        *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + n) = v.raw;
+    }
+}
+
+}  // namespace aa

@@ -22,3 +22,15 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16
 
 __device__ __forceinline__ float wave_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, src, 64); }
+
+// 64 zero bytes in device memory: what halo / tail lanes of an LDS-DMA tile load read instead of an activation.
+__device__ __attribute__((aligned(64))) u32x4 aa_zero_page_[4];
+__device__ __forceinline__ const void* zero_page() { return aa_zero_page_; }
+
+// LDS-DMA: every lane fetches 16 bytes from its own global address; the wave's 64 pieces land lane-linear
+// at lds_wave_base + lane*16 (wave-uniform base) without passing through VGPRs (global_load_lds_dwordx4).
+// Completion is tracked by vmcnt; a following __syncthreads() drains it.
+__device__ __forceinline__ void async_copy16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}

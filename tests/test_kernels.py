@@ -194,3 +194,50 @@ def test_softmax_rows_and_dpm_step(backend):
     close(x, 0.9 * xr + 0.2 * x0 + 0.05 * (x0 - x0r), tol=1e-5)
     close(x0p, x0, tol=1e-5)
     close(lp, x, tol=2e-3)
+
+
+# ---- shapes that take the LDS-DMA fast path of aa_conv_gemm (channels % 64 == 0, 16-byte output rows) ----
+@pytest.mark.parametrize("stride,pad,up_to,c1", [(1, 1, None, 0), (2, 1, None, 0), (1, 1, (9, 13), 0), (1, 1, None, 64), (2, 0, None, 0)])
+def test_conv3x3_dma_path(backend, stride, pad, up_to, c1):
+    n, h, w, cin, cout = 2, 5, 7, 64 + c1, 72
+    x, wt, b = rnd(n, cin, h, w, seed=41), rnd(cout, cin, 3, 3, scale=0.05, seed=42), rnd(cout, seed=43)
+    g = ops.conv3x3_geom(n, h, w, stride=stride, pad=pad, up_to=up_to)
+    temb = rnd(n, cout, seed=44)
+    res = rnd(g.rows, cout, seed=45)
+    tok = nhwc(x)
+    x0, x1 = (tok, None) if c1 == 0 else (tok[:, :64].contiguous(), tok[:, 64:].contiguous())
+    y = ops.conv_gemm(x0, ops.pack_weight(wt, b), g, x1=x1, rowvec=temb, rowvec_div=g.h_out * g.w_out, residual=res,
+                      act=AA_ACT_SILU, out_scale=0.5)
+    xr = x.float()
+    if up_to is not None:
+        xr = F.interpolate(xr, size=up_to, mode="nearest")
+    if pad == 0:
+        xr = F.pad(xr, (0, 1, 0, 1))
+    ref = F.conv2d(xr, wt.float(), b.float(), stride=stride, padding=pad) + temb.float()[:, :, None, None]
+    ref = (F.silu(nhwc(ref)).half().float() + res.float()) * 0.5
+    close(y, ref)
+
+
+def test_linear_and_tconv_dma_path(backend):
+    M, K, N = 300, 128, 320                       # n_pad 320 -> 64-wide tiles
+    x, w, b, r = rnd(M, K, seed=46), rnd(N, K, scale=0.1, seed=47), rnd(N, seed=48), rnd(M, N, seed=49)
+    y = ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M), residual=r)
+    close(y, x.float() @ w.float().t() + b.float() + r.float())
+    M, K, N = 260, 192, 256                       # 128-wide tiles
+    x, w, b = rnd(M, K, seed=50), rnd(N, K, scale=0.1, seed=51), rnd(N, seed=52)
+    close(ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M)), x.float() @ w.float().t() + b.float())
+    clips, frames, hw, c = 2, 5, 6, 64
+    x5 = rnd(clips, c, frames, hw, 1, seed=53)
+    wt, b = rnd(c, c, 3, 1, 1, scale=0.1, seed=54), rnd(c, seed=55)
+    tok = x5.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous()
+    y = ops.conv_gemm(tok, ops.pack_weight(wt, b), ops.tconv_geom(clips, frames, hw), residual=tok)
+    ref = F.conv3d(x5.float(), wt.float(), b.float(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, c) + tok.float()
+    close(y, ref)
+
+
+def test_geglu_dma_path_wide(backend):
+    M, K, D = 150, 64, 128
+    x, w, b, r = rnd(M, K, seed=56), rnd(2 * D, K, scale=0.2, seed=57), rnd(2 * D, seed=58), rnd(M, D, seed=59)
+    y = ops.conv_gemm(x, ops.pack_weight(w, b, geglu=True), ops.linear_geom(M), residual=r)
+    h = x.float() @ w.float().t() + b.float()
+    close(y, (h[:, :D] * F.gelu(h[:, D:])).half().float() + r.float())
