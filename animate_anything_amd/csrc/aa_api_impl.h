@@ -69,9 +69,9 @@ static int groupnorm_t(const AaGroupNorm& d, float* ws, int chunks, int apply_ch
 }
 
 static int gn_chunks(const AaGroupNorm& d) {
-    // aim for >= ~1024 workgroups, at least 64 tokens each
+    // aim for >= ~1024 workgroups, at least 16 tokens each
     int want = (1024 + d.n_groups_img - 1) / d.n_groups_img;
-    int cap = (d.tokens_per_group + 63) / 64;
+    int cap = (d.tokens_per_group + 15) / 16;
     int c = want < cap ? want : cap;
     return c < 1 ? 1 : c;
 }

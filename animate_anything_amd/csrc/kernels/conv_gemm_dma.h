@@ -165,23 +165,32 @@ __global__ void __launch_bounds__(CG_THREADS) conv_gemm_dma_kernel(const AaConvG
                 }
         }
     } else {
+        // rows of one tile fall into at most two row-vector groups when rowvec_div >= 128 (always true on
+        // the UNet path: rowvec_div = frames*H*W); otherwise divide per element.
+        const int m_base = tile_m * CG_BM;
+        const int g0 = m_base / p.rowvec_div;
+        const int g_edge = (g0 + 1) * p.rowvec_div;
+        const bool two_groups = p.rowvec_div >= CG_BM;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int nl = wn * (BN / 2) + j * 32 + col_l;
-            const int n = tile_n * BN + nl;
-            const bool c_ok = n < p.n_out;
-            const float bcol = (bias && c_ok && !p.bias_per_row) ? (float)bias[n] : 0.0f;
+            const int n = min(tile_n * BN + nl, p.n_out - 1);          // clamped: padded columns are never stored
+            const float bcol = (bias && !p.bias_per_row) ? (float)bias[n] : 0.0f;
+            float rv0 = 0.0f, rv1 = 0.0f;
+            if (rowvec && two_groups) {
+                const int gmax = (M - 1) / p.rowvec_div;
+                rv0 = (float)rowvec[(int64_t)min(g0, gmax) * p.n_out + n];
+                rv1 = (float)rowvec[(int64_t)min(g0 + 1, gmax) * p.n_out + n];
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rr = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
-                    const int m = tile_m * CG_BM + rr;
+                    const int m = min(m_base + rr, M - 1);
                     float v = acc[i][j][e] + bcol;
-                    if (c_ok && m < M) {
-                        if (p.bias_per_row && bias) v += (float)bias[m];
-                        if (rowvec) v += (float)rowvec[(int64_t)(m / p.rowvec_div) * p.n_out + n];
-                    }
+                    if (p.bias_per_row && bias) v += (float)bias[m];
+                    if (rowvec) v += two_groups ? (m < g_edge ? rv0 : rv1) : (float)rowvec[(int64_t)(m / p.rowvec_div) * p.n_out + n];
                     if (p.act == AA_ACT_SILU) v = silu_f(v);
                     sE[rr * LDE + nl] = (T)v;
                 }
