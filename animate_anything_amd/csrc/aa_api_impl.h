@@ -6,6 +6,7 @@
 #pragma once
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "aa_mi355.h"
 #include "kernels/conv_gemm.h"
 #include "kernels/conv_gemm_dma.h"
@@ -32,26 +33,74 @@ static int finish(const char* what) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Tile configurations of the LDS-DMA contraction kernel.  `rate` is the relative throughput of a tile
+// shape once the CUs are full (measured: the L2 -> LDS stream limits the narrow tiles); the chooser
+// minimises rounds(tiles / resident slots) * tile work / rate over the shapes that divide the packed width.
+struct CgCfg { int bm, bn, wm, wn, per_cu; float rate; };
+static const CgCfg kCgCfgs[] = {
+    {128, 64, 2, 2, 3, 0.70f},
+    {128, 128, 2, 2, 2, 1.00f},
+    {128, 320, 2, 2, 1, 1.30f},
+    {256, 256, 4, 2, 1, 1.45f},
+    {256, 320, 4, 2, 1, 1.55f},
+};
+constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
+
+static int g_tile_override = -2;   // -2: read AA_FORCE_CFG once; -1: automatic; >= 0: forced index
+static int cg_force_cfg() {
+    if (g_tile_override == -2) { const char* e = getenv("AA_FORCE_CFG"); g_tile_override = e ? atoi(e) : -1; }
+    return g_tile_override;
+}
+
+static int cg_choose(const AaConvGemm& d, int M) {
+    int best = -1;
+    double best_cost = 0.0;
+    const int forced = cg_force_cfg();
+    for (int i = 0; i < kNumCgCfgs; ++i) {
+        const CgCfg& c = kCgCfgs[i];
+        if (d.n_pad % c.bn) continue;
+        if (d.geglu && c.bn != 2 * d.geglu) continue;
+        if (forced == i) return i;
+        const double tiles = (double)((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
+        const double slots = 256.0 * c.per_cu;
+        const double rounds = (double)(long long)((tiles + slots - 1) / slots);
+        const double cost = rounds * c.bm * c.bn * c.per_cu / c.rate;
+        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+    }
+    return best;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static void cg_launch_dma(const AaConvGemm& d, int M, void* stream) {
+    const int tiles_n = d.n_pad / BN;
+    const dim3 grid(((M + BM - 1) / BM) * tiles_n), block(64 * WM * WN);
+    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN>), grid, block, cgd_lds_bytes(BM, BN), stream, d, M, tiles_n);
+}
+
 template <typename T>
 static int conv_gemm_t(const AaConvGemm& d, void* stream) {
-    const int64_t M64 = (int64_t)d.n_img * d.h_out * d.w_out;
-    const int M = (int)M64;
-    // BN = 128 unless the packed width only fills 64-column tiles (N = 320, 960, conv_out ...)
-    const bool bn128 = (d.n_pad % 128 == 0);
-    const int bn = bn128 ? 128 : 64;
-    if (d.geglu && !bn128) return fail(AA_E_SHAPE, "conv_gemm: GEGLU needs n_pad %% 128 == 0 (got %d)", d.n_pad);
-    const int tiles_m = (M + CG_BM - 1) / CG_BM;
-    const int tiles_n = d.n_pad / bn;
-    const dim3 grid(tiles_m * tiles_n), block(CG_THREADS);
+    const int M = (int)((int64_t)d.n_img * d.h_out * d.w_out);
     // LDS-DMA fast path: K tiles never straddle a filter tap / concat source, output rows are 16-byte chunks
     const int n_cols = d.geglu ? d.n_out / 2 : d.n_out;
     const bool dma = (d.c0 + d.c1) % 64 == 0 && d.c0 % 64 == 0 && d.out_dtype == d.dtype && n_cols % 8 == 0 &&
                      d.ldo % 8 == 0 && aligned16(d.out) && (!d.residual || (d.ldr % 8 == 0 && aligned16(d.residual)));
     if (dma) {
-        if (bn128) AA_LAUNCH((conv_gemm_dma_kernel<T, 128>), grid, block, cgd_lds_bytes(128), stream, d, M, tiles_n);
-        else       AA_LAUNCH((conv_gemm_dma_kernel<T, 64>), grid, block, cgd_lds_bytes(64), stream, d, M, tiles_n);
+        switch (cg_choose(d, M)) {
+            case 0: cg_launch_dma<T, 128, 64, 2, 2>(d, M, stream); break;
+            case 1: cg_launch_dma<T, 128, 128, 2, 2>(d, M, stream); break;
+            case 2: cg_launch_dma<T, 128, 320, 2, 2>(d, M, stream); break;
+            case 3: cg_launch_dma<T, 256, 256, 4, 2>(d, M, stream); break;
+            case 4: cg_launch_dma<T, 256, 320, 4, 2>(d, M, stream); break;
+            default: return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
+        }
         return finish("conv_gemm");
     }
+    if (d.geglu) return fail(AA_E_SHAPE, "conv_gemm: GEGLU needs the LDS-DMA path (channels %% 64 == 0, 16-byte rows)");
+    // generic gather path (odd channel counts: conv_in2, conv_out, VAE stem / head, fp32 scores)
+    const bool bn128 = (d.n_pad % 128 == 0);
+    const int bn = bn128 ? 128 : 64;
+    const int tiles_n = d.n_pad / bn;
+    const dim3 grid(((M + CG_BM - 1) / CG_BM) * tiles_n), block(CG_THREADS);
     if (bn128) AA_LAUNCH((conv_gemm_kernel<T, 128>), grid, block, cg_lds_bytes(128), stream, d, M, tiles_n);
     else       AA_LAUNCH((conv_gemm_kernel<T, 64>), grid, block, cg_lds_bytes(64), stream, d, M, tiles_n);
     return finish("conv_gemm");
@@ -94,6 +143,7 @@ static int attention_t(const AaAttention& d, void* stream) {
 extern "C" {
 
 int aa_version(void) { return AA_VERSION; }
+void aa_set_tile_override(int cfg) { aa::g_tile_override = cfg < 0 ? -1 : cfg; }
 const char* aa_last_error(void) { return aa::g_err; }
 
 int aa_conv_gemm(const AaConvGemm* d, void* stream) {

@@ -155,27 +155,6 @@ __global__ void __launch_bounds__(CG_THREADS) conv_gemm_kernel(const AaConvGemm 
     const T* resid = reinterpret_cast<const T*>(p.residual);
     const int col_l = lane & 31;
     const int row_l = 4 * (lane >> 5);
-    if (p.geglu) {
-        if constexpr (NT == 2) {
-            const int npk = tile_n * BN + wn * 64;            // packed column of the value block
-            const int oc = (npk >> 1) + col_l;                  // output column
-            const bool c_ok = (npk + col_l) < p.n_pad && oc < (p.n_out >> 1);
-            const float bv = (bias && c_ok) ? (float)bias[npk + col_l] : 0.0f;
-            const float bg = (bias && c_ok) ? (float)bias[npk + 32 + col_l] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = tile_m * CG_BM + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
-                    if (m < M && c_ok) {
-                        float v = (acc[i][0][e] + bv) * gelu_erf_f(acc[i][1][e] + bg);
-                        if (resid) v += (float)resid[(int64_t)m * p.ldr + oc];
-                        store_out<T>(p.out, p.out_dtype, (int64_t)m * p.ldo + oc, v * p.out_scale);
-                    }
-                }
-        }
-        return;
-    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = tile_n * BN + wn * (BN / 2) + j * 32 + col_l;

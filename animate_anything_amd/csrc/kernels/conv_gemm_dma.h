@@ -1,7 +1,8 @@
 // Implicit-GEMM convolution / linear kernel, LDS-DMA edition (fast path of aa_conv_gemm).
 //
-// Same tiling as conv_gemm.h (128 x BN tile, K step 64, 2x2 waves, v_mfma_f32_32x32x16) but both operand
-// tiles travel HBM -> LDS with `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass):
+// A BM x BN output tile per workgroup, K step 64, WM x WN wavefronts each owning a (BM/WM) x (BN/WN) block
+// of v_mfma_f32_32x32x16 accumulators.  Both operand tiles travel HBM/L2 -> LDS with
+// `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass):
 //  * every wave instruction deposits 64 lanes x 16 B = 8 tile rows x 128 B, lane-linear; the im2col gather,
 //    the conv halo and the M / K tails are expressed in the per-lane SOURCE address (halo lanes read a
 //    16-byte zero page);
@@ -11,8 +12,12 @@
 //    c0 % 64 == 0): tap / source / channel base are then wave-uniform scalars and the per-row pixel offsets
 //    are recomputed only when the tap changes;
 //  * two LDS buffers, tile t+1 in flight while tile t is multiplied, one barrier per K step;
-//  * epilogue: bias / time-embedding row vector / SiLU / GEGLU in registers, tile parked in LDS as storage
-//    dtype, read back row-major so residual loads and output stores are full 16-byte, row-contiguous.
+//  * epilogue: bias / time-embedding row vector / SiLU in registers, tile parked in LDS as storage dtype
+//    (128 rows at a time), read back row-major so GEGLU pairing (value | gate halves of the tile), residual
+//    loads and output stores are full 16-byte, row-contiguous.
+// Tile shapes (see aa_api_impl.h for the choice): the L2 -> LDS stream is the measured limiter of the
+// 128x128 / 128x64 tiles (~13.5 TB/s aggregate), so wide tiles (128x320, 256x320, 256x256) that raise the
+// FLOP per staged byte are preferred whenever the tile count still fills the 256 CUs.
 #pragma once
 #include "dev.h"
 #include "aa_mi355.h"
@@ -20,21 +25,30 @@
 
 namespace aa {
 
-__host__ __device__ inline int cgd_lds_bytes(int bn) { return 2 * (CG_BM + bn) * CG_BK * 2; }
+__host__ __device__ inline int cgd_lds_bytes(int bm, int bn) {
+    const int operands = 2 * (bm + bn) * CG_BK * 2;
+    const int staging = 128 * (bn + 8) * 2;           // >= WM*32 rows of the epilogue staging tile
+    return operands > staging ? operands : staging;
+}
 
-template <typename T, int BN>
-__global__ void __launch_bounds__(CG_THREADS) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n) {
-    constexpr int NT = BN / 64;
-    constexpr int BJ = BN / 32;          // weight-row DMA instructions per wave
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n) {
+    constexpr int NW = WM * WN;
+    constexpr int THREADS = 64 * NW;
+    constexpr int MI = BM / WM / 32;     // 32-row accumulator blocks per wave
+    constexpr int NI = BN / WN / 32;     // 32-column accumulator blocks per wave
+    constexpr int AJ = BM / 8 / NW;      // activation-row DMA instructions per wave
+    constexpr int BJ = BN / 8 / NW;      // weight-row DMA instructions per wave
     constexpr int ROWB = CG_BK * 2;      // bytes per LDS tile row (128)
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
     char* smem = dyn_smem();
-    char* sA = smem;                                  // [2][128][128 B]
-    char* sB = smem + 2 * CG_BM * ROWB;               // [2][BN][128 B]
+    char* sA = smem;                                  // [2][BM][128 B]
+    char* sB = smem + 2 * BM * ROWB;                  // [2][BN][128 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7;
@@ -47,15 +61,15 @@ __global__ void __launch_bounds__(CG_THREADS) conv_gemm_dma_kernel(const AaConvG
     const int nk = p.k_pad / CG_BK;
     const bool resize = (p.h_virt != p.h_in) || (p.w_virt != p.w_in);
 
-    // ---- DMA geometry: this lane feeds LDS rows (wave*32 + j*8 + lane/8), 16-byte position lane%8 ----
+    // ---- DMA geometry: this lane feeds LDS rows (wave*AJ*8 + j*8 + lane/8), 16-byte position lane%8 ----
     const int lrow = lane >> 3, lpos = lane & 7;
-    int row_img[4], row_iy[4], row_ix[4], kslot[4];
-    bool row_ok[4];
-    int64_t pix[4];
+    int row_img[AJ], row_iy[AJ], row_ix[AJ], kslot[AJ];
+    bool row_ok[AJ];
+    int aoff[AJ];                        // element offset of this lane's 16-byte piece inside the source, -1 = zero page
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rr = wave * 32 + j * 8 + lrow;
-        const int m = tile_m * CG_BM + rr;
+    for (int j = 0; j < AJ; ++j) {
+        const int rr = (wave * AJ + j) * 8 + lrow;
+        const int m = tile_m * BM + rr;
         row_ok[j] = m < M;
         const int mm = row_ok[j] ? m : 0;
         const int x = mm % p.w_out;
@@ -65,17 +79,20 @@ __global__ void __launch_bounds__(CG_THREADS) conv_gemm_dma_kernel(const AaConvG
         row_iy[j] = y * p.stride - p.pad_h;
         row_ix[j] = x * p.stride - p.pad_w;
         kslot[j] = lpos ^ ((rr >> 1) & 7);
-        pix[j] = -1;
+        aoff[j] = -1;
     }
-    const T* wsrc[BJ];
+    // weight panel of this tile: 32-bit element offsets (a packed panel is far below 2^31 elements)
+    const T* wtile = reinterpret_cast<const T*>(p.w) + (int64_t)tile_n * BN * p.k_pad;
+    int woff[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int rr = wave * (BN / 4) + j * 8 + lrow;
-        wsrc[j] = reinterpret_cast<const T*>(p.w) + (int64_t)(tile_n * BN + rr) * p.k_pad + (lpos ^ ((rr >> 1) & 7)) * 8;
+        const int rr = (wave * BJ + j) * 8 + lrow;
+        woff[j] = rr * p.k_pad + (lpos ^ ((rr >> 1) & 7)) * 8;
     }
     const T* zero = reinterpret_cast<const T*>(zero_page());
 
     int cur_tap = -1;
+    int pixel[AJ];                       // source pixel of each fed row for the current tap (-1 = halo / tail)
     auto issue = [&](int kt, int buf) {
         const int k0 = kt * CG_BK;
         const int tap = k0 / ctot;                     // wave-uniform
@@ -85,137 +102,140 @@ __global__ void __launch_bounds__(CG_THREADS) conv_gemm_dma_kernel(const AaConvG
             const int dy = tap / p.kw, dx = tap - dy * p.kw;
             const bool tap_ok = tap < p.kh * p.kw;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < AJ; ++j) {
                 const int iy = row_iy[j] + dy, ix = row_ix[j] + dx;
                 const bool ok = tap_ok && row_ok[j] && (unsigned)iy < (unsigned)p.h_virt && (unsigned)ix < (unsigned)p.w_virt;
                 int sy = iy, sx = ix;
                 if (resize) { sy = (iy * p.h_in) / p.h_virt; sx = (ix * p.w_in) / p.w_virt; }
-                pix[j] = ok ? ((int64_t)row_img[j] * p.h_in + sy) * p.w_in + sx : -1;
+                pixel[j] = ok ? (row_img[j] * p.h_in + sy) * p.w_in + sx : -1;
             }
         }
         const T* src; int cs, cc;
         if (cb < p.c0) { src = reinterpret_cast<const T*>(p.a0); cs = p.c0; cc = cb; }
         else           { src = reinterpret_cast<const T*>(p.a1); cs = p.c1; cc = cb - p.c0; }
-        char* a = sA + buf * CG_BM * ROWB + wave * 32 * ROWB;
-        char* b = sB + buf * BN * ROWB + wave * (BN / 4) * ROWB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const T* g = pix[j] >= 0 ? src + pix[j] * cs + cc + kslot[j] * 8 : zero;
+        for (int j = 0; j < AJ; ++j) aoff[j] = pixel[j] >= 0 ? pixel[j] * cs + cc + kslot[j] * 8 : -1;
+        char* a = sA + buf * BM * ROWB + wave * AJ * 8 * ROWB;
+        char* b = sB + buf * BN * ROWB + wave * BJ * 8 * ROWB;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const T* g = aoff[j] >= 0 ? src + aoff[j] : zero;
             async_copy16(g, a + j * 8 * ROWB);
         }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) async_copy16(wsrc[j] + (int64_t)kt * CG_BK, b + j * 8 * ROWB);
+        for (int j = 0; j < BJ; ++j) async_copy16(wtile + woff[j] + kt * CG_BK, b + j * 8 * ROWB);
     };
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     // fragment read offsets (bytes): row = base + (lane&31), k-slot ks*2 + (lane>>5), un-swizzled per row
     const int frow = lane & 31, fh = lane >> 5;
-    int a_off[2], b_off[NT], a_swz[2], b_swz[NT];
+    int a_off[MI], b_off[NI], a_swz[MI], b_swz[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int rr = wm * 64 + i * 32 + frow; a_off[i] = rr * ROWB; a_swz[i] = (rr >> 1) & 7; }
+    for (int i = 0; i < MI; ++i) { const int rr = wm * (BM / WM) + i * 32 + frow; a_off[i] = rr * ROWB; a_swz[i] = (rr >> 1) & 7; }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) { const int rr = wn * (BN / 2) + j * 32 + frow; b_off[j] = rr * ROWB; b_swz[j] = (rr >> 1) & 7; }
+    for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + frow; b_off[j] = rr * ROWB; b_swz[j] = (rr >> 1) & 7; }
 
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                 // tile kt has landed (DMA drained before the barrier), buffer (kt+1)&1 is free
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* a = sA + (kt & 1) * CG_BM * ROWB;
+        const char* a = sA + (kt & 1) * BM * ROWB;
         const char* b = sB + (kt & 1) * BN * ROWB;
 #pragma unroll
         for (int ks = 0; ks < CG_BK / 16; ++ks) {
-            u32x4 fa[2], fb[NT];
+            u32x4 fa[MI], fb[NI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const u32x4*>(a + a_off[i] + (((ks * 2 + fh) ^ a_swz[i]) << 4));
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const u32x4*>(a + a_off[i] + (((ks * 2 + fh) ^ a_swz[i]) << 4));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b + b_off[j] + (((ks * 2 + fh) ^ b_swz[j]) << 4));
+            for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b + b_off[j] + (((ks * 2 + fh) ^ b_swz[j]) << 4));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_32x32x16(T(), fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fa[i], fb[j], acc[i][j]);
         }
     }
-    __syncthreads();                     // operand buffers are dead: reuse them for the output tile
 
-    // ---- epilogue part 1 (registers): bias, row vector, activation, GEGLU -> storage dtype tile in LDS ----
-    constexpr int LDE = BN + 8;          // padded row length (elements) of the staged output tile
+    // ---- epilogue: pass i stages accumulator block-row i of EVERY wave (WM*32 tile rows) through an LDS
+    // tile [WM*32][BN+8] of storage dtype; acc[i] is dead after pass i, so register pressure only falls ----
+    constexpr int LDE = BN + 8;
+    constexpr int PROWS = WM * 32;                       // tile rows staged per pass
     T* sE = reinterpret_cast<T*>(smem);
     const T* bias = reinterpret_cast<const T*>(p.bias);
     const T* rowvec = reinterpret_cast<const T*>(p.rowvec);
-    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-    const int out_cols = p.geglu ? BN / 2 : BN;          // tile width in output columns
-    if (p.geglu) {
-        if constexpr (NT == 2) {
-            const int npk = tile_n * BN + wn * 64;
-            const float bv = bias ? (float)bias[npk + col_l] : 0.0f;
-            const float bg = bias ? (float)bias[npk + 32 + col_l] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rr = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
-                    sE[rr * LDE + wn * 32 + col_l] = (T)((acc[i][0][e] + bv) * gelu_erf_f(acc[i][1][e] + bg));
-                }
-        }
-    } else {
-        // rows of one tile fall into at most two row-vector groups when rowvec_div >= 128 (always true on
-        // the UNet path: rowvec_div = frames*H*W); otherwise divide per element.
-        const int m_base = tile_m * CG_BM;
-        const int g0 = m_base / p.rowvec_div;
-        const int g_edge = (g0 + 1) * p.rowvec_div;
-        const bool two_groups = p.rowvec_div >= CG_BM;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int nl = wn * (BN / 2) + j * 32 + col_l;
-            const int n = min(tile_n * BN + nl, p.n_out - 1);          // clamped: padded columns are never stored
-            const float bcol = (bias && !p.bias_per_row) ? (float)bias[n] : 0.0f;
-            float rv0 = 0.0f, rv1 = 0.0f;
-            if (rowvec && two_groups) {
-                const int gmax = (M - 1) / p.rowvec_div;
-                rv0 = (float)rowvec[(int64_t)min(g0, gmax) * p.n_out + n];
-                rv1 = (float)rowvec[(int64_t)min(g0 + 1, gmax) * p.n_out + n];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rr = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
-                    const int m = min(m_base + rr, M - 1);
-                    float v = acc[i][j][e] + bcol;
-                    if (p.bias_per_row && bias) v += (float)bias[m];
-                    if (rowvec) v += two_groups ? (m < g_edge ? rv0 : rv1) : (float)rowvec[(int64_t)(m / p.rowvec_div) * p.n_out + n];
-                    if (p.act == AA_ACT_SILU) v = silu_f(v);
-                    sE[rr * LDE + nl] = (T)v;
-                }
-        }
-    }
-    __syncthreads();
-
-    // ---- epilogue part 2 (row-major, 16 B per lane): + residual, * scale, store ----
     const T* resid = reinterpret_cast<const T*>(p.residual);
     T* out = reinterpret_cast<T*>(p.out);
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    const int m_tile = tile_m * BM;
+    const int g0 = m_tile / p.rowvec_div;
+    const int g_edge = (g0 + 1) * p.rowvec_div;
+    // rows of one tile fall into at most two row-vector groups when rowvec_div >= BM (always true on the
+    // UNet path: rowvec_div = frames*H*W); otherwise divide per element.
+    const bool two_groups = p.rowvec_div >= BM;
+    const int out_cols = p.geglu ? BN / 2 : BN;          // tile width in output columns
     const int n_cols = p.geglu ? (p.n_out >> 1) : p.n_out;
     const int chunks_per_row = out_cols >> 3;
     const int col0 = tile_n * out_cols;
-    for (int c = tid; c < CG_BM * chunks_per_row; c += CG_THREADS) {
-        const int rr = c / chunks_per_row, ch = c - rr * chunks_per_row;
-        const int m = tile_m * CG_BM + rr, n = col0 + ch * 8;
-        if (m >= M || n >= n_cols) continue;
-        Pack8<T> v; v.raw = *reinterpret_cast<const u32x4*>(sE + rr * LDE + ch * 8);
-        if (resid || p.out_scale != 1.0f) {
-            Pack8<T> rs; rs.raw = u32x4{0u, 0u, 0u, 0u};
-            if (resid) rs.raw = *reinterpret_cast<const u32x4*>(resid + (int64_t)m * p.ldr + n);
+
+    // per-column terms are the same in every pass: hoist them
+    float bcol[NI], rv0[NI], rv1[NI];
+    int nbj[NI];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v.e[e] = (T)(((float)v.e[e] + (float)rs.e[e]) * p.out_scale);
+    for (int j = 0; j < NI; ++j) {
+        const int n = min(tile_n * BN + wn * (BN / WN) + j * 32 + col_l, p.n_pad - 1);
+        nbj[j] = p.geglu ? n : min(n, p.n_out - 1);       // GEGLU bias is packed like the weights
+        bcol[j] = (bias && !p.bias_per_row) ? (float)bias[nbj[j]] : 0.0f;
+        rv0[j] = 0.0f; rv1[j] = 0.0f;
+        if (rowvec && two_groups) {
+            const int gmax = (M - 1) / p.rowvec_div;
+            rv0[j] = (float)rowvec[(int64_t)min(g0, gmax) * p.n_out + nbj[j]];
+            rv1[j] = (float)rowvec[(int64_t)min(g0 + 1, gmax) * p.n_out + nbj[j]];
         }
-        *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + n) = v.raw;
+    }
+
+#pragma unroll
+    for (int ps = 0; ps < MI; ++ps) {
+        __syncthreads();                                  // previous users of the LDS region are done
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nl = wn * (BN / WN) + j * 32 + col_l;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rl = wm * 32 + (e & 3) + 8 * (e >> 2) + row_l;               // staged row
+                const int m = min(m_tile + wm * (BM / WM) + ps * 32 + (e & 3) + 8 * (e >> 2) + row_l, M - 1);
+                float v = acc[ps][j][e] + bcol[j];
+                if (p.bias_per_row && bias) v += (float)bias[m];
+                if (rowvec) v += two_groups ? (m < g_edge ? rv0[j] : rv1[j]) : (float)rowvec[(int64_t)(m / p.rowvec_div) * p.n_out + nbj[j]];
+                if (p.act == AA_ACT_SILU) v = silu_f(v);
+                sE[rl * LDE + nl] = (T)v;
+            }
+        }
+        __syncthreads();
+        // row-major read-back, 16 B per lane: GEGLU pairing, + residual, * scale, store
+        for (int c = tid; c < PROWS * chunks_per_row; c += THREADS) {
+            const int rl = c / chunks_per_row, ch = c - rl * chunks_per_row;
+            const int m = m_tile + (rl >> 5) * (BM / WM) + ps * 32 + (rl & 31), n = col0 + ch * 8;
+            if (m >= M || n >= n_cols) continue;
+            Pack8<T> v; v.raw = *reinterpret_cast<const u32x4*>(sE + rl * LDE + ch * 8);
+            if (p.geglu) {
+                Pack8<T> gt; gt.raw = *reinterpret_cast<const u32x4*>(sE + rl * LDE + out_cols + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.e[e] = (T)((float)v.e[e] * gelu_erf_f((float)gt.e[e]));
+            }
+            if (resid || p.out_scale != 1.0f) {
+                Pack8<T> rs; rs.raw = u32x4{0u, 0u, 0u, 0u};
+                if (resid) rs.raw = *reinterpret_cast<const u32x4*>(resid + (int64_t)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.e[e] = (T)(((float)v.e[e] + (float)rs.e[e]) * p.out_scale);
+            }
+            *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + n) = v.raw;
+        }
     }
 }
 

@@ -62,7 +62,7 @@ class PackedWeight:
     kh: int
     kw: int
     cin: int          # channels per tap as stored (after padding to a multiple of 8)
-    geglu: bool = False
+    geglu: int = 0    # 0, or the value/gate interleave granularity of a GEGLU projection
 
     @property
     def n_pad(self):
@@ -77,7 +77,7 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     """Pack an nn.Linear [n,k], nn.Conv2d [n,c,kh,kw] or nn.Conv3d [n,c,kt,1,1] weight.
 
     GEGLU (diffusers `GEGLU.proj`, rows [0,d) = value, [d,2d) = gate) is re-ordered into alternating
-    blocks of 32 value rows / 32 gate rows so that both halves of a pair land in one wave's tile."""
+    blocks of G value rows / G gate rows (G = 160 or 64) so that both halves of a pair land in one tile."""
     w = weight.detach()
     if w.dim() == 2:
         n, kh, kw, cin = w.shape[0], 1, 1, w.shape[1]
@@ -99,8 +99,9 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     b = None if bias is None else bias.detach()
     if geglu:
         d = n // 2
-        assert d % 32 == 0, "GEGLU inner width must be a multiple of 32"
-        val = torch.arange(d, device=w.device).reshape(d // 32, 1, 32)
+        gran = 160 if d % 160 == 0 else 64          # half the width of the tile shape that will own the pair
+        assert d % gran == 0, "GEGLU inner width must be a multiple of 64"
+        val = torch.arange(d, device=w.device).reshape(d // gran, 1, gran)
         src = torch.cat([val, val + d], dim=1).reshape(-1)
         w2 = w2[src]
         b = None if b is None else b[src]
@@ -109,7 +110,7 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     out[:n, :k] = w2
     if b is not None and geglu and n_pad != n:
         b = torch.nn.functional.pad(b, (0, n_pad - n))
-    return PackedWeight(out.contiguous(), None if b is None else b.contiguous(), n, kh, kw, cpad, geglu)
+    return PackedWeight(out.contiguous(), None if b is None else b.contiguous(), n, kh, kw, cpad, gran if geglu else 0)
 
 
 # ------------------------------------------------------------------------------------- contraction

@@ -58,7 +58,8 @@ const char* aa_last_error(void);
  * diffusers ResnetBlock2D); activation; GEGLU pairing (diffusers GEGLU: value * gelu_erf(gate));
  * + residual[m, n]; * out_scale; store as `out_dtype`.
  * W is pre-packed by the host: [n_pad, k_pad] row-major, k ordered (tap, channel), zero padded,
- * and for GEGLU interleaved in blocks of 32 value rows / 32 gate rows.
+ * and for GEGLU interleaved in blocks of `geglu` value rows / `geglu` gate rows (geglu = 64 or 160:
+ * half the width of the tile that will own the pair).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct AaConvGemm {
     const void* a0;
@@ -76,7 +77,7 @@ typedef struct AaConvGemm {
     int32_t rowvec_div;
     int32_t ldo, ldr;
     int32_t act;           /* AA_ACT_* */
-    int32_t geglu;         /* 1: columns are (32 value | 32 gate) blocks, output has n_out/2 columns */
+    int32_t geglu;         /* 0, or G: packed columns are (G value | G gate) blocks, output has n_out/2 columns */
     int32_t bias_per_row;
     int32_t dtype;         /* AA_F16 | AA_BF16: activations + weights */
     int32_t out_dtype;     /* AA_F16 | AA_BF16 (== dtype) or AA_F32 */
@@ -84,6 +85,10 @@ typedef struct AaConvGemm {
 } AaConvGemm;
 
 int aa_conv_gemm(const AaConvGemm* d, void* stream);
+
+/* Tuning / test aid: force tile shape `cfg` (index into the table in csrc/aa_api_impl.h) for every
+ * following aa_conv_gemm call whose packed width it divides; cfg < 0 restores the automatic choice. */
+void aa_set_tile_override(int cfg);
 
 /* ----------------------------------------------------------------------------------------------
  * aa_groupnorm: y = [silu]( (x - mean) * rstd * gamma + beta ), statistics per (image group, channel

@@ -15,6 +15,7 @@ p = argparse.ArgumentParser()
 p.add_argument("--dtype", default="fp16")
 p.add_argument("--only", default="")
 p.add_argument("--reps", type=int, default=10)
+p.add_argument("--cfg-sweep", action="store_true", help="time every contraction shape under every forced tile shape")
 a = p.parse_args()
 DT = torch.float16 if a.dtype == "fp16" else torch.bfloat16
 dev = "cuda"
@@ -35,6 +36,24 @@ def timeit(fn, reps=a.reps):
 
 def rnd(*s):
     return torch.randn(*s, device=dev, dtype=torch.float32).to(DT)
+
+
+from animate_anything_amd import _lib  # noqa: E402
+CFGS = [(128, 64), (128, 128), (128, 320), (256, 256), (256, 320)]
+
+
+def sweep(name, fn, flops, n_pad, geglu=0):
+    """fn() under the automatic tile choice and under every tile shape that divides n_pad."""
+    lib = _lib.get()
+    report(name + " [auto]", timeit(fn), flops=flops)
+    if not a.cfg_sweep:
+        return
+    for i, (bm, bn) in enumerate(CFGS):
+        if n_pad % bn or (geglu and bn != 2 * geglu):
+            continue
+        lib.aa_set_tile_override(i)
+        report(f"{name} [{bm}x{bn}]", timeit(fn), flops=flops)
+    lib.aa_set_tile_override(-1)
 
 
 def report(name, secs, flops=None, bytes_=None):
@@ -62,7 +81,7 @@ def bench_linear(name, M, K, Nout, geglu=False):
     x, w = rnd(M, K), rnd(Nout, K) * 0.05
     pw = ops.pack_weight(w, rnd(Nout), geglu=geglu)
     g = ops.linear_geom(M)
-    report(f"{name} M={M} K={K} N={Nout}", timeit(lambda: ops.conv_gemm(x, pw, g)), flops=2.0 * M * K * Nout)
+    sweep(f"{name} M={M} K={K} N={Nout}", lambda: ops.conv_gemm(x, pw, g), 2.0 * M * K * Nout, pw.n_pad, pw.geglu)
 
 
 def bench_conv(name, n, hw, cin, cout, stride=1, up=False, c1=0):
@@ -72,8 +91,8 @@ def bench_conv(name, n, hw, cin, cout, stride=1, up=False, c1=0):
     x1 = rnd(n * hw * hw, c1) if c1 else None
     pw = ops.pack_weight(rnd(cout, cin, 3, 3) * 0.02, rnd(cout))
     g = ops.conv3x3_geom(n, hw, hw, stride=stride, up_to=(2 * hw, 2 * hw) if up else None)
-    report(f"{name} n={n} {hw}x{hw} {cin}->{cout} s{stride}{' up' if up else ''}",
-           timeit(lambda: ops.conv_gemm(x0, pw, g, x1=x1)), flops=2.0 * g.rows * 9 * cin * cout)
+    sweep(f"{name} n={n} {hw}x{hw} {cin}->{cout} s{stride}{' up' if up else ''}",
+          lambda: ops.conv_gemm(x0, pw, g, x1=x1), 2.0 * g.rows * 9 * cin * cout, pw.n_pad)
 
 
 def bench_tconv(name, hw, c):
@@ -82,7 +101,7 @@ def bench_tconv(name, hw, c):
     x = rnd(N * hw * hw, c)
     pw = ops.pack_weight(rnd(c, c, 3, 1, 1) * 0.02, rnd(c))
     g = ops.tconv_geom(B, T, hw * hw)
-    report(f"{name} {hw}x{hw} C={c}", timeit(lambda: ops.conv_gemm(x, pw, g)), flops=2.0 * g.rows * 3 * c * c)
+    sweep(f"{name} {hw}x{hw} C={c}", lambda: ops.conv_gemm(x, pw, g), 2.0 * g.rows * 3 * c * c, pw.n_pad)
 
 
 for c, hw in LEVELS[:3]:

@@ -241,3 +241,31 @@ def test_geglu_dma_path_wide(backend):
     y = ops.conv_gemm(x, ops.pack_weight(w, b, geglu=True), ops.linear_geom(M), residual=r)
     h = x.float() @ w.float().t() + b.float()
     close(y, (h[:, :D] * F.gelu(h[:, D:])).half().float() + r.float())
+
+
+@pytest.mark.parametrize("cfg,N", [(0, 320), (1, 640), (2, 320), (3, 256), (4, 640)])
+def test_dma_tile_shapes(backend, cfg, N):
+    """Every tile shape of the LDS-DMA kernel (forced), conv3x3 with halo + M tail + residual."""
+    from animate_anything_amd import _lib
+    n, h, w, cin = 3, 9, 11, 64              # M = 297: one 256-row tile + tail / three 128-row tiles
+    x, wt, b = rnd(n, cin, h, w, seed=61), rnd(N, cin, 3, 3, scale=0.05, seed=62), rnd(N, seed=63)
+    g = ops.conv3x3_geom(n, h, w)
+    res, temb = rnd(g.rows, N, seed=64), rnd(n, N, seed=65)
+    lib = _lib.get()
+    lib.aa_set_tile_override(cfg)
+    try:
+        y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res, rowvec=temb, rowvec_div=h * w)
+    finally:
+        lib.aa_set_tile_override(-1)
+    ref = nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1) + temb.float()[:, :, None, None]).half().float() + res.float()
+    close(y, ref)
+
+
+@pytest.mark.parametrize("D", [160, 320])
+def test_geglu_wide_tiles(backend, D):
+    M, K = 200, 128
+    x, w, b = rnd(M, K, seed=66), rnd(2 * D, K, scale=0.1, seed=67), rnd(2 * D, seed=68)
+    pw = ops.pack_weight(w, b, geglu=True)
+    assert pw.geglu == 160
+    h = x.float() @ w.float().t() + b.float()
+    close(ops.conv_gemm(x, pw, ops.linear_geom(M)), h[:, :D] * F.gelu(h[:, D:]))
