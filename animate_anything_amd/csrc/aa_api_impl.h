@@ -38,11 +38,12 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // minimises rounds(tiles / resident slots) * tile work / rate over the shapes that divide the packed width.
 struct CgCfg { int bm, bn, wm, wn, per_cu; float rate; };
 static const CgCfg kCgCfgs[] = {
-    {128, 64, 2, 2, 3, 0.70f},
-    {128, 128, 2, 2, 2, 1.00f},
-    {128, 320, 2, 2, 1, 1.30f},
-    {256, 256, 4, 2, 1, 1.45f},
-    {256, 320, 4, 2, 1, 1.55f},
+    {128, 64, 2, 2, 3, 0.78f},     // 0
+    {128, 128, 2, 2, 2, 0.90f},    // 1
+    {192, 256, 3, 2, 1, 1.05f},    // 2
+    {256, 256, 4, 2, 1, 1.10f},    // 3
+    {256, 320, 4, 2, 1, 1.10f},    // 4
+    {192, 320, 3, 2, 1, 1.05f},    // 5
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -55,7 +56,7 @@ static int cg_force_cfg() {
 static int cg_choose(const AaConvGemm& d, int M) {
     int best = -1;
     double best_cost = 0.0;
-    const int forced = cg_force_cfg();
+    const int forced = d.tile >= 0 ? d.tile : cg_force_cfg();
     for (int i = 0; i < kNumCgCfgs; ++i) {
         const CgCfg& c = kCgCfgs[i];
         if (d.n_pad % c.bn) continue;
@@ -88,9 +89,10 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
         switch (cg_choose(d, M)) {
             case 0: cg_launch_dma<T, 128, 64, 2, 2>(d, M, stream); break;
             case 1: cg_launch_dma<T, 128, 128, 2, 2>(d, M, stream); break;
-            case 2: cg_launch_dma<T, 128, 320, 2, 2>(d, M, stream); break;
+            case 2: cg_launch_dma<T, 192, 256, 3, 2>(d, M, stream); break;
             case 3: cg_launch_dma<T, 256, 256, 4, 2>(d, M, stream); break;
             case 4: cg_launch_dma<T, 256, 320, 4, 2>(d, M, stream); break;
+            case 5: cg_launch_dma<T, 192, 320, 3, 2>(d, M, stream); break;
             default: return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
         }
         return finish("conv_gemm");

@@ -1,12 +1,16 @@
 // Flash-style attention for gfx950, head_dim 64 (see include/aa_mi355.h: aa_attention).
 //
 // One wavefront owns 32 query rows of one (sequence, head); NW wavefronts of a workgroup share each
-// 64-key K/V tile through LDS.  The score tile is computed TRANSPOSED, S^T = K Q^T, so that in the
+// 64-key K/V tile through LDS (double buffered, one barrier per tile, next tile's global loads in flight
+// during the current tile's math).  The score tile is computed TRANSPOSED, S^T = K Q^T, so that in the
 // 32x32 MFMA result layout (col = lane&31) every lane owns one query row: the online-softmax max and
 // sum are register-local (one xor-32 shuffle joins the two half-waves), and the exponentiated
-// registers are, unchanged, the B operand of O^T = V^T P^T.  V is written to LDS transposed with its
-// keys permuted inside each 16-key chunk (quads 1 and 2 swapped) so the matching A operand is a
-// single ds_read_b128.  Softmax runs in base 2 on scores pre-multiplied by scale*log2(e).
+// registers are, unchanged, the B operand of O^T = V^T P^T.
+// V is written to LDS transposed, [d][key], with (a) the keys permuted inside each 16-key chunk (quads 1
+// and 2 swapped) so the matching A operand is a single ds_read_b128, and (b) the 8-key chunks of row d
+// XOR-ed with x(d) = ((d>>3) + 2*(d&7)) & 7, which makes both the 2-byte transposing stores and the
+// 16-byte fragment reads bank-conflict free on the unpadded 128-byte rows.
+// Softmax runs in base 2: p = exp2(s*c - m*c), c = scale*log2(e), max taken on raw scores.
 #pragma once
 #include "dev.h"
 #include "aa_mi355.h"
@@ -14,9 +18,11 @@
 namespace aa {
 
 constexpr int AT_KT = 64;       // keys per tile
-constexpr int AT_LDS = 72;      // padded LDS row (elements)
+constexpr int AT_LDK = 72;      // padded K row (elements)
+constexpr int AT_LDV = 64;      // V^T row (elements), XOR-swizzled instead of padded
+constexpr int AT_BUF = AT_KT * AT_LDK + 64 * AT_LDV;    // elements per (K, V^T) buffer pair
 
-__host__ __device__ inline int attn_lds_bytes() { return 2 * AT_KT * AT_LDS * 2; }
+__host__ __device__ inline int attn_lds_bytes() { return 2 * AT_BUF * 2; }
 
 template <typename T>
 __device__ __forceinline__ const T* attn_row(const AaAttnOperand& x, int o, int i, int pos, int head) {
@@ -24,12 +30,13 @@ __device__ __forceinline__ const T* attn_row(const AaAttnOperand& x, int o, int 
     return reinterpret_cast<const T*>(x.ptr) + row * x.ld + x.col0 + head * 64;
 }
 
+__device__ __forceinline__ int vt_swz(int d) { return ((d >> 3) + 2 * (d & 7)) & 7; }
+
 template <typename T, int NW>
 __global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p) {
     constexpr int THREADS = 64 * NW;
     constexpr int SLOTS = (AT_KT * 8) / THREADS;     // 16-byte K (and V) slots staged per thread
-    T* sK = reinterpret_cast<T*>(dyn_smem());        // [64 keys][72]
-    T* sVt = sK + AT_KT * AT_LDS;                    // [64 d][72]  (keys permuted)
+    T* lds = reinterpret_cast<T*>(dyn_smem());
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, ql = lane & 31;
@@ -69,32 +76,40 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p)
             rk[s] = a; rv[s] = b;
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](int buf) {
+        T* sK = lds + buf * AT_BUF;
+        T* sVt = sK + AT_KT * AT_LDK;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int sl = tid + s * THREADS;
             const int key = sl >> 3, dseg = sl & 7;
-            *reinterpret_cast<u32x4*>(sK + key * AT_LDS + dseg * 8) = rk[s];
+            *reinterpret_cast<u32x4*>(sK + key * AT_LDK + dseg * 8) = rk[s];
             const int quad = (key >> 2) & 3;
             const int pos = (key & ~15) | ((((quad & 1) << 1) | (quad >> 1)) << 2) | (key & 3);
             Pack8<T> v; v.raw = rv[s];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sVt[(dseg * 8 + e) * AT_LDS + pos] = v.e[e];
+            for (int e = 0; e < 8; ++e) {
+                const int d = dseg * 8 + e;
+                sVt[d * AT_LDV + (pos ^ (vt_swz(d) << 3))] = v.e[e];
+            }
         }
     };
 
     f32x16 oacc[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.0f; oacc[1][e] = 0.0f; }
-    float m_run = -1.0e30f, l_run = 0.0f;
+    float m_run = -1.0e30f, l_run = 0.0f;       // running max of RAW scores, running sum of this half-wave's keys
 
     const int ntiles = (p.kv_len + AT_KT - 1) / AT_KT;
+    const bool ragged = (p.kv_len & (AT_KT - 1)) != 0;
     fetch(0);
+    stash(0);
+    __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
-        stash();
-        __syncthreads();
         if (kt + 1 < ntiles) fetch(kt + 1);
         if (wave_active) {
+            const T* sK = lds + (kt & 1) * AT_BUF;
+            const T* sVt = sK + AT_KT * AT_LDK;
             f32x16 sacc[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -102,25 +117,34 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p)
                 for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.0f;
 #pragma unroll
                 for (int dk = 0; dk < 4; ++dk) {
-                    const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + (32 * kb + ql) * AT_LDS + 16 * dk + 8 * h);
+                    const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + (32 * kb + ql) * AT_LDK + 16 * dk + 8 * h);
                     sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], sacc[kb]);
                 }
             }
-            // scale, mask, running max
-            float mloc = -1.0e30f;
+            if (ragged && kt == ntiles - 1) {           // mask the keys past kv_len (last tile only)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = kt * AT_KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (key >= p.kv_len) sacc[kb][e] = -1.0e30f;
+                    }
+            }
+            float mloc = sacc[0][0];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = kt * AT_KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const float s = key < p.kv_len ? sacc[kb][e] * sl2e : -1.0e30f;
-                    sacc[kb][e] = s;
-                    mloc = fmaxf(mloc, s);
-                }
+                for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[kb][e]);
             mloc = fmaxf(mloc, wave_shfl_xor(mloc, 32));
             const float m_new = fmaxf(m_run, mloc);
-            const float alpha = exp2f(m_run - m_new);
-            m_run = m_new;
+            if (wave_any(m_new > m_run)) {              // some row's max moved: rescale the accumulators
+                const float alpha = exp2f((m_run - m_new) * sl2e);
+                l_run *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+                m_run = m_new;
+            }
+            const float mc = m_run * sl2e;
             float psum = 0.0f;
             u32x4 pf[4];
 #pragma unroll
@@ -130,23 +154,23 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p)
                     Pack8<T> pk;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float pe = exp2f(sacc[kb][8 * c + e] - m_new);
+                        const float pe = exp2f(sacc[kb][8 * c + e] * sl2e - mc);
                         psum += pe;
                         pk.e[e] = (T)pe;
                     }
                     pf[2 * kb + c] = pk.raw;
                 }
-            l_run = l_run * alpha + psum;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+            l_run += psum;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch) {
-                    const u32x4 vf = *reinterpret_cast<const u32x4*>(sVt + (32 * db + ql) * AT_LDS + 16 * ch + 8 * h);
+                    const int d = 32 * db + ql;
+                    const u32x4 vf = *reinterpret_cast<const u32x4*>(sVt + d * AT_LDV + (((2 * ch + h) ^ vt_swz(d)) << 3));
                     oacc[db] = mfma_32x32x16(T(), vf, pf[ch], oacc[db]);
                 }
         }
+        if (kt + 1 < ntiles) stash((kt + 1) & 1);
         __syncthreads();
     }
 

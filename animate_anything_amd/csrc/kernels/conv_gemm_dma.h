@@ -37,10 +37,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
     constexpr int THREADS = 64 * NW;
     constexpr int MI = BM / WM / 32;     // 32-row accumulator blocks per wave
     constexpr int NI = BN / WN / 32;     // 32-column accumulator blocks per wave
-    constexpr int AJ = BM / 8 / NW;      // activation-row DMA instructions per wave
-    constexpr int BJ = BN / 8 / NW;      // weight-row DMA instructions per wave
+    constexpr int GA = BM / 8, GB = BN / 8;          // 8-row DMA groups of the activation / weight tile
+    constexpr int AJ = (GA + NW - 1) / NW;           // DMA instructions per wave (group = wave + NW*j, guarded)
+    constexpr int BJ = (GB + NW - 1) / NW;
     constexpr int ROWB = CG_BK * 2;      // bytes per LDS tile row (128)
-    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile shape");
     char* smem = dyn_smem();
     char* sA = smem;                                  // [2][BM][128 B]
     char* sB = smem + 2 * BM * ROWB;                  // [2][BN][128 B]
@@ -61,16 +62,16 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
     const int nk = p.k_pad / CG_BK;
     const bool resize = (p.h_virt != p.h_in) || (p.w_virt != p.w_in);
 
-    // ---- DMA geometry: this lane feeds LDS rows (wave*AJ*8 + j*8 + lane/8), 16-byte position lane%8 ----
+    // ---- DMA geometry: this lane feeds LDS rows ((wave + NW*j)*8 + lane/8), 16-byte position lane%8 ----
     const int lrow = lane >> 3, lpos = lane & 7;
     int row_img[AJ], row_iy[AJ], row_ix[AJ], kslot[AJ];
     bool row_ok[AJ];
     int aoff[AJ];                        // element offset of this lane's 16-byte piece inside the source, -1 = zero page
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-        const int rr = (wave * AJ + j) * 8 + lrow;
+        const int rr = (wave + NW * j) * 8 + lrow;
         const int m = tile_m * BM + rr;
-        row_ok[j] = m < M;
+        row_ok[j] = m < M && rr < BM;
         const int mm = row_ok[j] ? m : 0;
         const int x = mm % p.w_out;
         const int t = mm / p.w_out;
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
     int woff[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int rr = (wave * BJ + j) * 8 + lrow;
+        const int rr = (wave + NW * j) * 8 + lrow;
         woff[j] = rr * p.k_pad + (lpos ^ ((rr >> 1) & 7)) * 8;
     }
     const T* zero = reinterpret_cast<const T*>(zero_page());
@@ -115,15 +116,16 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
         else           { src = reinterpret_cast<const T*>(p.a1); cs = p.c1; cc = cb - p.c0; }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) aoff[j] = pixel[j] >= 0 ? pixel[j] * cs + cc + kslot[j] * 8 : -1;
-        char* a = sA + buf * BM * ROWB + wave * AJ * 8 * ROWB;
-        char* b = sB + buf * BN * ROWB + wave * BJ * 8 * ROWB;
+        char* a = sA + buf * BM * ROWB + wave * 8 * ROWB;
+        char* b = sB + buf * BN * ROWB + wave * 8 * ROWB;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const T* g = aoff[j] >= 0 ? src + aoff[j] : zero;
-            async_copy16(g, a + j * 8 * ROWB);
+            if (GA % NW == 0 || wave + NW * j < GA) async_copy16(g, a + j * NW * 8 * ROWB);      // wave-uniform guard
         }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) async_copy16(wtile + woff[j] + kt * CG_BK, b + j * 8 * ROWB);
+        for (int j = 0; j < BJ; ++j)
+            if (GB % NW == 0 || wave + NW * j < GB) async_copy16(wtile + woff[j] + kt * CG_BK, b + j * NW * 8 * ROWB);
     };
 
     f32x16 acc[MI][NI];

@@ -82,6 +82,7 @@ typedef struct AaConvGemm {
     int32_t dtype;         /* AA_F16 | AA_BF16: activations + weights */
     int32_t out_dtype;     /* AA_F16 | AA_BF16 (== dtype) or AA_F32 */
     float out_scale;
+    int32_t tile;          /* -1: library picks the tile shape; >= 0: index into the tile table (autotuning) */
 } AaConvGemm;
 
 int aa_conv_gemm(const AaConvGemm* d, void* stream);

@@ -39,7 +39,8 @@ def rnd(*s):
 
 
 from animate_anything_amd import _lib  # noqa: E402
-CFGS = [(128, 64), (128, 128), (128, 320), (256, 256), (256, 320)]
+CFGS = list(ops.TILE_TABLE)
+ops.AUTOTUNE = False
 
 
 def sweep(name, fn, flops, n_pad, geglu=0):

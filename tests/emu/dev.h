@@ -157,6 +157,15 @@ inline float wave_shfl(float v, int src) {
     return out;
 }
 
+inline bool wave_any(bool pred) {
+    bool out = false;
+    emu::wave_collective(&pred, [&](const std::vector<const void*>& s) {
+        const int lanes = std::min<int>(64, (int)emu::blk()->fibers.size() - 64 * (emu::linear_tid() >> 6));
+        for (int l = 0; l < lanes; ++l) out = out || *static_cast<const bool*>(s[l]);
+    });
+    return out;
+}
+
 template <typename T>
 inline f32x16 emu_mfma_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
     struct Ops { u32x4 a, b; } mine{a, b};

@@ -243,11 +243,11 @@ def test_geglu_dma_path_wide(backend):
     close(y, (h[:, :D] * F.gelu(h[:, D:])).half().float() + r.float())
 
 
-@pytest.mark.parametrize("cfg,N", [(0, 320), (1, 640), (2, 320), (3, 256), (4, 640)])
+@pytest.mark.parametrize("cfg,N", [(0, 320), (1, 640), (2, 256), (3, 256), (4, 640), (5, 320)])
 def test_dma_tile_shapes(backend, cfg, N):
     """Every tile shape of the LDS-DMA kernel (forced), conv3x3 with halo + M tail + residual."""
     from animate_anything_amd import _lib
-    n, h, w, cin = 3, 9, 11, 64              # M = 297: one 256-row tile + tail / three 128-row tiles
+    n, h, w, cin = 3, 9, 11, 64              # M = 297: one 256-row tile + tail / 192 + tail / three 128-row tiles
     x, wt, b = rnd(n, cin, h, w, seed=61), rnd(N, cin, 3, 3, scale=0.05, seed=62), rnd(N, seed=63)
     g = ops.conv3x3_geom(n, h, w)
     res, temb = rnd(g.rows, N, seed=64), rnd(n, N, seed=65)
