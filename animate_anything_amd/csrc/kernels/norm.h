@@ -58,7 +58,18 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_stats_kernel(const AaGro
 #pragma unroll
         for (int e = 0; e < 8; ++e) { a[e] = 0.0f; b[e] = 0.0f; }
         if (active) {
-            for (int t = t_begin + roff; t < t_end; t += rows_per_pass) {
+            int t = t_begin + roff;
+            for (; t + rows_per_pass < t_end; t += 2 * rows_per_pass) {      // two independent rows in flight
+                Pack8<T> v, w;
+                v.raw = load8<T>(x0, x1, p.c0, p.c1, base + t, slot * 8);
+                w.raw = load8<T>(x0, x1, p.c0, p.c1, base + t + rows_per_pass, slot * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v.e[e], g = (float)w.e[e];
+                    a[e] += f + g; b[e] += f * f + g * g;
+                }
+            }
+            if (t < t_end) {
                 Pack8<T> v; v.raw = load8<T>(x0, x1, p.c0, p.c1, base + t, slot * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float f = (float)v.e[e]; a[e] += f; b[e] += f * f; }
@@ -141,19 +152,38 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_apply_kernel(const AaGro
     const T* x0 = reinterpret_cast<const T*>(p.x0);
     const T* x1 = reinterpret_cast<const T*>(p.x1);
     T* y = reinterpret_cast<T*>(p.y);
-    const int64_t total = (int64_t)(t_end - t_begin) * S;
-    for (int64_t i = tid; i < total; i += GN_THREADS) {
-        const int t = t_begin + (int)(i / S);
-        const int slot = (int)(i % S);
-        Pack8<T> v; v.raw = load8<T>(x0, x1, p.c0, p.c1, base + t, slot * 8);
-        Pack8<T> o;
+    // thread -> fixed 16-byte channel slot (its scale/shift stay in registers), rows strided: no div/mod in
+    // the streaming loop, two independent rows in flight per iteration
+    const int rows_per_pass = S <= GN_THREADS ? GN_THREADS / S : 1;
+    for (int s0 = 0; s0 < S; s0 += GN_THREADS) {
+        const int slot = s0 + (S <= GN_THREADS ? tid % S : tid);
+        const int roff = S <= GN_THREADS ? tid / S : 0;
+        if (slot >= S || roff >= rows_per_pass) continue;
+        float sc[8], sh[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float f = (float)v.e[e] * s_scale[slot * 8 + e] + s_shift[slot * 8 + e];
-            if (p.silu) f = f / (1.0f + __expf(-f));
-            o.e[e] = (T)f;
+        for (int e = 0; e < 8; ++e) { sc[e] = s_scale[slot * 8 + e]; sh[e] = s_shift[slot * 8 + e]; }
+        auto norm8 = [&](Pack8<T> v) {
+            Pack8<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v.e[e] * sc[e] + sh[e];
+                if (p.silu) f = f / (1.0f + __expf(-f));
+                o.e[e] = (T)f;
+            }
+            return o;
+        };
+        int t = t_begin + roff;
+        for (; t + rows_per_pass < t_end; t += 2 * rows_per_pass) {
+            Pack8<T> va, vb;
+            va.raw = load8<T>(x0, x1, p.c0, p.c1, base + t, slot * 8);
+            vb.raw = load8<T>(x0, x1, p.c0, p.c1, base + t + rows_per_pass, slot * 8);
+            *reinterpret_cast<u32x4*>(y + (base + t) * C + slot * 8) = norm8(va).raw;
+            *reinterpret_cast<u32x4*>(y + (base + t + rows_per_pass) * C + slot * 8) = norm8(vb).raw;
         }
-        *reinterpret_cast<u32x4*>(y + (base + t) * C + slot * 8) = o.raw;
+        if (t < t_end) {
+            Pack8<T> va; va.raw = load8<T>(x0, x1, p.c0, p.c1, base + t, slot * 8);
+            *reinterpret_cast<u32x4*>(y + (base + t) * C + slot * 8) = norm8(va).raw;
+        }
     }
 }
 
