@@ -98,6 +98,7 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
         return finish("conv_gemm");
     }
     if (d.geglu) return fail(AA_E_SHAPE, "conv_gemm: GEGLU needs the LDS-DMA path (channels %% 64 == 0, 16-byte rows)");
+    if (d.k_order) return fail(AA_E_SHAPE, "conv_gemm: chunk-major weights need the LDS-DMA path (channels %% 64 == 0, 16-byte rows)");
     // generic gather path (odd channel counts: conv_in2, conv_out, VAE stem / head, fp32 scores)
     const bool bn128 = (d.n_pad % 128 == 0);
     const int bn = bn128 ? 128 : 64;
@@ -132,10 +133,10 @@ static int attention_t(const AaAttention& d, void* stream) {
     const int nseq = d.n_outer * d.n_inner;
     if (d.q_len > 64) {
         const dim3 grid((d.q_len + 127) / 128, d.heads, nseq);
-        AA_LAUNCH((attention_kernel<T, 4>), grid, dim3(256), attn_lds_bytes(), stream, d);
+        AA_LAUNCH((attention_kernel<T, 4>), grid, dim3(256), attn_lds_bytes(d.kv_len), stream, d);
     } else {
         const dim3 grid((d.q_len + 31) / 32, d.heads, nseq);
-        AA_LAUNCH((attention_kernel<T, 1>), grid, dim3(64), attn_lds_bytes(), stream, d);
+        AA_LAUNCH((attention_kernel<T, 1>), grid, dim3(64), attn_lds_bytes(d.kv_len), stream, d);
     }
     return finish("attention");
 }

@@ -22,7 +22,8 @@ constexpr int AT_LDK = 72;      // padded K row (elements)
 constexpr int AT_LDV = 64;      // V^T row (elements), XOR-swizzled instead of padded
 constexpr int AT_BUF = AT_KT * AT_LDK + 64 * AT_LDV;    // elements per (K, V^T) buffer pair
 
-__host__ __device__ inline int attn_lds_bytes() { return 2 * AT_BUF * 2; }
+// one (K, V^T) buffer when the sequence fits a single tile (temporal / text attention), else two
+__host__ __device__ inline int attn_lds_bytes(int kv_len) { return (kv_len > AT_KT ? 2 : 1) * AT_BUF * 2; }
 
 template <typename T>
 __device__ __forceinline__ const T* attn_row(const AaAttnOperand& x, int o, int i, int pos, int head) {

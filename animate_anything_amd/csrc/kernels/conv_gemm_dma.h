@@ -95,9 +95,12 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
     int cur_tap = -1;
     int pixel[AJ];                       // source pixel of each fed row for the current tap (-1 = halo / tail)
     auto issue = [&](int kt, int buf) {
-        const int k0 = kt * CG_BK;
-        const int tap = k0 / ctot;                     // wave-uniform
-        const int cb = k0 - tap * ctot;
+        // K order (wave-uniform scalars): tap-major (tap, channel) or, for multi-tap filters packed
+        // chunk-major, (64-channel chunk, tap, channel) - consecutive K steps then re-read the same
+        // activation slab shifted by one tap, which keeps it L2-resident across the 9 taps.
+        int tap, cb;
+        if (p.k_order) { const int taps = p.kh * p.kw; const int chunk = kt / taps; tap = kt - chunk * taps; cb = chunk * CG_BK; }
+        else           { const int k0 = kt * CG_BK; tap = k0 / ctot; cb = k0 - tap * ctot; }
         if (tap != cur_tap) {
             cur_tap = tap;
             const int dy = tap / p.kw, dx = tap - dy * p.kw;

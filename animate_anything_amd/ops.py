@@ -105,6 +105,7 @@ class PackedWeight:
     kw: int
     cin: int          # channels per tap as stored (after padding to a multiple of 8)
     geglu: int = 0    # 0, or the value/gate interleave granularity of a GEGLU projection
+    k_order: int = 0  # 0: K = (tap, channel); 1: K = (64-channel chunk, tap, channel)
 
     @property
     def n_pad(self):
@@ -137,6 +138,11 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     if cpad != cin:
         w4 = torch.nn.functional.pad(w4, (0, cpad - cin))
     k = kh * kw * cpad
+    k_order = 0
+    if kh * kw > 1 and cpad % 64 == 0:
+        # multi-tap filter: chunk-major K so the 9 (3) taps of one 64-channel slab are consecutive K steps
+        w4 = w4.reshape(n, kh * kw, cpad // 64, 64).permute(0, 2, 1, 3)
+        k_order = 1
     w2 = w4.reshape(n, k)
     b = None if bias is None else bias.detach()
     if geglu:
@@ -152,7 +158,7 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     out[:n, :k] = w2
     if b is not None and geglu and n_pad != n:
         b = torch.nn.functional.pad(b, (0, n_pad - n))
-    return PackedWeight(out.contiguous(), None if b is None else b.contiguous(), n, kh, kw, cpad, gran if geglu else 0)
+    return PackedWeight(out.contiguous(), None if b is None else b.contiguous(), n, kh, kw, cpad, gran if geglu else 0, k_order)
 
 
 # ------------------------------------------------------------------------------------- contraction
@@ -228,6 +234,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.ldr = 0 if residual is None else residual.stride(0)
     d.act, d.geglu, d.bias_per_row = act, int(pw.geglu), int(bias_per_row)
     d.dtype, d.out_dtype, d.out_scale = _DT[x0.dtype], _DT[odt], out_scale
+    d.k_order = pw.k_order
     d.tile = -1
     if AUTOTUNE and x0.is_cuda:
         key = (d.dtype, g.n_img, g.h_in, g.w_in, d.h_virt, d.w_virt, g.h_out, g.w_out, g.stride, pw.kh, pw.kw, c0, c1,

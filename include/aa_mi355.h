@@ -57,7 +57,8 @@ const char* aa_last_error(void);
  * Epilogue, in order: + bias[n] (or bias[m]); + rowvec[m / rowvec_div, n] (time embedding,
  * diffusers ResnetBlock2D); activation; GEGLU pairing (diffusers GEGLU: value * gelu_erf(gate));
  * + residual[m, n]; * out_scale; store as `out_dtype`.
- * W is pre-packed by the host: [n_pad, k_pad] row-major, k ordered (tap, channel), zero padded,
+ * W is pre-packed by the host: [n_pad, k_pad] row-major, k ordered (tap, channel) - or, see k_order,
+ * (64-channel chunk, tap, channel) for multi-tap filters - zero padded,
  * and for GEGLU interleaved in blocks of `geglu` value rows / `geglu` gate rows (geglu = 64 or 160:
  * half the width of the tile that will own the pair).
  * ---------------------------------------------------------------------------------------------- */
@@ -82,6 +83,7 @@ typedef struct AaConvGemm {
     int32_t dtype;         /* AA_F16 | AA_BF16: activations + weights */
     int32_t out_dtype;     /* AA_F16 | AA_BF16 (== dtype) or AA_F32 */
     float out_scale;
+    int32_t k_order;       /* 0: packed K is (tap, channel); 1: (64-channel chunk, tap, channel) - LDS-DMA path only */
     int32_t tile;          /* -1: library picks the tile shape; >= 0: index into the tile table (autotuning) */
 } AaConvGemm;
 
