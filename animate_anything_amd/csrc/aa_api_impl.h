@@ -36,14 +36,19 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tile configurations of the LDS-DMA contraction kernel.  `rate` is the relative throughput of a tile
 // shape once the CUs are full (measured: the L2 -> LDS stream limits the narrow tiles); the chooser
 // minimises rounds(tiles / resident slots) * tile work / rate over the shapes that divide the packed width.
-struct CgCfg { int bm, bn, wm, wn, per_cu; float rate; };
+struct CgCfg { int bm, bn, wm, wn, bk, stages, per_cu; float rate; };
 static const CgCfg kCgCfgs[] = {
-    {128, 64, 2, 2, 3, 0.78f},     // 0
-    {128, 128, 2, 2, 2, 0.90f},    // 1
-    {192, 256, 3, 2, 1, 1.05f},    // 2
-    {256, 256, 4, 2, 1, 1.10f},    // 3
-    {256, 320, 4, 2, 1, 1.10f},    // 4
-    {192, 320, 3, 2, 1, 1.05f},    // 5
+    {128, 64, 2, 2, 64, 2, 3, 0.78f},     // 0
+    {128, 128, 2, 2, 64, 2, 2, 0.90f},    // 1
+    {192, 256, 3, 2, 64, 2, 1, 1.05f},    // 2
+    {256, 256, 4, 2, 64, 2, 1, 1.10f},    // 3
+    {256, 320, 4, 2, 64, 2, 1, 1.10f},    // 4
+    {192, 320, 3, 2, 64, 2, 1, 1.05f},    // 5
+    {256, 320, 4, 2, 32, 4, 1, 1.15f},    // 6  deep ring (3 tiles in flight)
+    {256, 256, 4, 2, 32, 4, 1, 1.15f},    // 7
+    {128, 128, 2, 2, 32, 4, 2, 0.95f},    // 8
+    {128, 64, 2, 2, 32, 4, 3, 0.80f},     // 9
+    {192, 320, 3, 2, 32, 4, 1, 1.10f},    // 10
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -71,11 +76,11 @@ static int cg_choose(const AaConvGemm& d, int M) {
     return best;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES>
 static void cg_launch_dma(const AaConvGemm& d, int M, void* stream) {
     const int tiles_n = d.n_pad / BN;
     const dim3 grid(((M + BM - 1) / BM) * tiles_n), block(64 * WM * WN);
-    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN>), grid, block, cgd_lds_bytes(BM, BN), stream, d, M, tiles_n);
+    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, M, tiles_n);
 }
 
 template <typename T>
@@ -87,12 +92,17 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
                      d.ldo % 8 == 0 && aligned16(d.out) && (!d.residual || (d.ldr % 8 == 0 && aligned16(d.residual)));
     if (dma) {
         switch (cg_choose(d, M)) {
-            case 0: cg_launch_dma<T, 128, 64, 2, 2>(d, M, stream); break;
-            case 1: cg_launch_dma<T, 128, 128, 2, 2>(d, M, stream); break;
-            case 2: cg_launch_dma<T, 192, 256, 3, 2>(d, M, stream); break;
-            case 3: cg_launch_dma<T, 256, 256, 4, 2>(d, M, stream); break;
-            case 4: cg_launch_dma<T, 256, 320, 4, 2>(d, M, stream); break;
-            case 5: cg_launch_dma<T, 192, 320, 3, 2>(d, M, stream); break;
+            case 0: cg_launch_dma<T, 128, 64, 2, 2, 64, 2>(d, M, stream); break;
+            case 1: cg_launch_dma<T, 128, 128, 2, 2, 64, 2>(d, M, stream); break;
+            case 2: cg_launch_dma<T, 192, 256, 3, 2, 64, 2>(d, M, stream); break;
+            case 3: cg_launch_dma<T, 256, 256, 4, 2, 64, 2>(d, M, stream); break;
+            case 4: cg_launch_dma<T, 256, 320, 4, 2, 64, 2>(d, M, stream); break;
+            case 5: cg_launch_dma<T, 192, 320, 3, 2, 64, 2>(d, M, stream); break;
+            case 6: cg_launch_dma<T, 256, 320, 4, 2, 32, 4>(d, M, stream); break;
+            case 7: cg_launch_dma<T, 256, 256, 4, 2, 32, 4>(d, M, stream); break;
+            case 8: cg_launch_dma<T, 128, 128, 2, 2, 32, 4>(d, M, stream); break;
+            case 9: cg_launch_dma<T, 128, 64, 2, 2, 32, 4>(d, M, stream); break;
+            case 10: cg_launch_dma<T, 192, 320, 3, 2, 32, 4>(d, M, stream); break;
             default: return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
         }
         return finish("conv_gemm");

@@ -106,8 +106,9 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p)
     fetch(0);
     stash(0);
     __syncthreads();
+    constexpr bool PREFETCH = NW > 1;    // one-wave workgroups stage 8 slots per thread: keep those registers free
     for (int kt = 0; kt < ntiles; ++kt) {
-        if (kt + 1 < ntiles) fetch(kt + 1);
+        if (PREFETCH && kt + 1 < ntiles) fetch(kt + 1);
         if (wave_active) {
             const T* sK = lds + (kt & 1) * AT_BUF;
             const T* sVt = sK + AT_KT * AT_LDK;
@@ -171,7 +172,10 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p)
                     oacc[db] = mfma_32x32x16(T(), vf, pf[ch], oacc[db]);
                 }
         }
-        if (kt + 1 < ntiles) stash((kt + 1) & 1);
+        if (kt + 1 < ntiles) {
+            if (!PREFETCH) fetch(kt + 1);
+            stash((kt + 1) & 1);
+        }
         __syncthreads();
     }
 

@@ -1,23 +1,23 @@
 // Implicit-GEMM convolution / linear kernel, LDS-DMA edition (fast path of aa_conv_gemm).
 //
-// A BM x BN output tile per workgroup, K step 64, WM x WN wavefronts each owning a (BM/WM) x (BN/WN) block
-// of v_mfma_f32_32x32x16 accumulators.  Both operand tiles travel HBM/L2 -> LDS with
-// `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass):
-//  * every wave instruction deposits 64 lanes x 16 B = 8 tile rows x 128 B, lane-linear; the im2col gather,
-//    the conv halo and the M / K tails are expressed in the per-lane SOURCE address (halo lanes read a
-//    16-byte zero page);
+// A BM x BN output tile per workgroup, K step BK (64 or 32), WM x WN wavefronts each owning a
+// (BM/WM) x (BN/WN) block of v_mfma_f32_32x32x16 accumulators, a ring of STAGES LDS buffers.
+// Both operand tiles travel HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR round trip, no ds_write):
+//  * every wave instruction deposits 64 lanes x 16 B, lane-linear = RPI tile rows of BK*2 bytes; the im2col
+//    gather, the conv halo and the M / K tails are expressed in the per-lane SOURCE address (halo lanes read
+//    a 16-byte zero page);
 //  * bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle applied on the source
-//    side (lane l of row r fetches k-slot (l&7) ^ ((r>>1)&7)) and undone on the read side;
+//    side (lane of row r, 16-byte position s fetches k-slot s ^ swz(r)) and undone on the read side;
 //  * requires the K tile to sit inside one filter tap and one concat source ((c0+c1) % 64 == 0 and
 //    c0 % 64 == 0): tap / source / channel base are then wave-uniform scalars and the per-row pixel offsets
 //    are recomputed only when the tap changes;
-//  * two LDS buffers, tile t+1 in flight while tile t is multiplied, one barrier per K step;
+//  * pipeline: STAGES-1 tiles are in flight ahead of the one being multiplied.  The measured limiter of the
+//    2-stage version is the DMA round trip under load (~1.5-2.5 us against a ~1.2 us MFMA phase), so the
+//    deeper rings wait with a COUNTED `s_waitcnt vmcnt(n)` (only the oldest tile must have landed) and a raw
+//    `s_barrier` (a __syncthreads() would drain every DMA); one barrier per K step;
 //  * epilogue: bias / time-embedding row vector / SiLU in registers, tile parked in LDS as storage dtype
-//    (128 rows at a time), read back row-major so GEGLU pairing (value | gate halves of the tile), residual
-//    loads and output stores are full 16-byte, row-contiguous.
-// Tile shapes (see aa_api_impl.h for the choice): the L2 -> LDS stream is the measured limiter of the
-// 128x128 / 128x64 tiles (~13.5 TB/s aggregate), so wide tiles (128x320, 256x320, 256x256) that raise the
-// FLOP per staged byte are preferred whenever the tile count still fills the 256 CUs.
+//    (one accumulator block-row of every wave at a time), read back row-major so GEGLU pairing (value | gate
+//    halves of the tile), residual loads and output stores are full 16-byte, row-contiguous.
 #pragma once
 #include "dev.h"
 #include "aa_mi355.h"
@@ -25,26 +25,33 @@
 
 namespace aa {
 
-__host__ __device__ inline int cgd_lds_bytes(int bm, int bn) {
-    const int operands = 2 * (bm + bn) * CG_BK * 2;
-    const int staging = 128 * (bn + 8) * 2;           // >= WM*32 rows of the epilogue staging tile
+__host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages) {
+    const int operands = stages * (bm + bn) * bk * 2 + 1024;     // + dummy DMA landing zone
+    const int staging = 128 * (bn + 8) * 2;                      // >= WM*32 rows of the epilogue staging tile
     return operands > staging ? operands : staging;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES>
 __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n) {
     constexpr int NW = WM * WN;
     constexpr int THREADS = 64 * NW;
     constexpr int MI = BM / WM / 32;     // 32-row accumulator blocks per wave
     constexpr int NI = BN / WN / 32;     // 32-column accumulator blocks per wave
-    constexpr int GA = BM / 8, GB = BN / 8;          // 8-row DMA groups of the activation / weight tile
-    constexpr int AJ = (GA + NW - 1) / NW;           // DMA instructions per wave (group = wave + NW*j, guarded)
+    constexpr int ROWB = BK * 2;         // bytes per LDS tile row (128 or 64)
+    constexpr int SPR = BK / 8;          // 16-byte slots per row (8 or 4)
+    constexpr int RPI = 64 / SPR;        // tile rows deposited by one wave DMA instruction (8 or 16)
+    constexpr int RPB = 256 / ROWB;      // tile rows per 256-byte LDS bank row (2 or 4)
+    constexpr int GA = BM / RPI, GB = BN / RPI;          // DMA groups of the activation / weight tile
+    constexpr int AJ = (GA + NW - 1) / NW;               // DMA instructions per wave (group = wave + NW*j)
     constexpr int BJ = (GB + NW - 1) / NW;
-    constexpr int ROWB = CG_BK * 2;      // bytes per LDS tile row (128)
-    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile shape");
+    constexpr int PER_TILE = AJ + BJ;                    // every wave issues exactly this many per tile
+    constexpr int DIST = STAGES - 1;                     // tiles in flight ahead of the multiply
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % RPI == 0 && BN % RPI == 0, "tile shape");
+    static_assert(BK == 64 || BK == 32, "K step");
+    static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * PER_TILE <= 63, "pipeline depth");
     char* smem = dyn_smem();
-    char* sA = smem;                                  // [2][BM][128 B]
-    char* sB = smem + 2 * BM * ROWB;                  // [2][BN][128 B]
+    char* dummy = smem + STAGES * STAGE_BYTES;           // where surplus (guarded-out) DMA instructions land
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -59,17 +66,17 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
     const int tile_n = logical - tile_m * tiles_n;
 
     const int ctot = p.c0 + p.c1;
-    const int nk = p.k_pad / CG_BK;
+    const int nk = p.k_pad / BK;
     const bool resize = (p.h_virt != p.h_in) || (p.w_virt != p.w_in);
 
-    // ---- DMA geometry: this lane feeds LDS rows ((wave + NW*j)*8 + lane/8), 16-byte position lane%8 ----
-    const int lrow = lane >> 3, lpos = lane & 7;
+    // ---- DMA geometry: this lane feeds LDS rows ((wave + NW*j)*RPI + lane/SPR), 16-byte position lane%SPR ----
+    const int lrow = lane / SPR, lpos = lane % SPR;
     int row_img[AJ], row_iy[AJ], row_ix[AJ], kslot[AJ];
     bool row_ok[AJ];
     int aoff[AJ];                        // element offset of this lane's 16-byte piece inside the source, -1 = zero page
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-        const int rr = (wave + NW * j) * 8 + lrow;
+        const int rr = (wave + NW * j) * RPI + lrow;
         const int m = tile_m * BM + rr;
         row_ok[j] = m < M && rr < BM;
         const int mm = row_ok[j] ? m : 0;
@@ -79,7 +86,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
         row_img[j] = t / p.h_out;
         row_iy[j] = y * p.stride - p.pad_h;
         row_ix[j] = x * p.stride - p.pad_w;
-        kslot[j] = lpos ^ ((rr >> 1) & 7);
+        kslot[j] = lpos ^ ((rr / RPB) % SPR);
         aoff[j] = -1;
     }
     // weight panel of this tile: 32-bit element offsets (a packed panel is far below 2^31 elements)
@@ -87,8 +94,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
     int woff[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int rr = (wave + NW * j) * 8 + lrow;
-        woff[j] = rr * p.k_pad + (lpos ^ ((rr >> 1) & 7)) * 8;
+        const int rr = (wave + NW * j) * RPI + lrow;
+        woff[j] = rr * p.k_pad + (lpos ^ ((rr / RPB) % SPR)) * 8;
     }
     const T* zero = reinterpret_cast<const T*>(zero_page());
 
@@ -98,9 +105,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
         // K order (wave-uniform scalars): tap-major (tap, channel) or, for multi-tap filters packed
         // chunk-major, (64-channel chunk, tap, channel) - consecutive K steps then re-read the same
         // activation slab shifted by one tap, which keeps it L2-resident across the 9 taps.
+        const int k0 = kt * BK;
         int tap, cb;
-        if (p.k_order) { const int taps = p.kh * p.kw; const int chunk = kt / taps; tap = kt - chunk * taps; cb = chunk * CG_BK; }
-        else           { const int k0 = kt * CG_BK; tap = k0 / ctot; cb = k0 - tap * ctot; }
+        if (p.k_order) { const int taps = p.kh * p.kw; const int unit = k0 >> 6; const int chunk = unit / taps;
+                         tap = unit - chunk * taps; cb = chunk * 64 + (k0 & 63); }
+        else           { tap = k0 / ctot; cb = k0 - tap * ctot; }
         if (tap != cur_tap) {
             cur_tap = tap;
             const int dy = tap / p.kw, dx = tap - dy * p.kw;
@@ -119,16 +128,21 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
         else           { src = reinterpret_cast<const T*>(p.a1); cs = p.c1; cc = cb - p.c0; }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) aoff[j] = pixel[j] >= 0 ? pixel[j] * cs + cc + kslot[j] * 8 : -1;
-        char* a = sA + buf * BM * ROWB + wave * 8 * ROWB;
-        char* b = sB + buf * BN * ROWB + wave * 8 * ROWB;
+        char* a = smem + buf * STAGE_BYTES + wave * RPI * ROWB;
+        char* b = smem + buf * STAGE_BYTES + BM * ROWB + wave * RPI * ROWB;
+        // every wave issues exactly PER_TILE instructions (vmcnt bookkeeping): groups past the tile edge are
+        // pointed at the zero page / the dummy landing zone (wave-uniform choice)
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const T* g = aoff[j] >= 0 ? src + aoff[j] : zero;
-            if (GA % NW == 0 || wave + NW * j < GA) async_copy16(g, a + j * NW * 8 * ROWB);      // wave-uniform guard
+            const bool real = (GA % NW == 0) || (wave + NW * j < GA);
+            const T* g = (real && aoff[j] >= 0) ? src + aoff[j] : zero;
+            async_copy16(g, real ? a + j * NW * RPI * ROWB : dummy);
         }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j)
-            if (GB % NW == 0 || wave + NW * j < GB) async_copy16(wtile + woff[j] + kt * CG_BK, b + j * NW * 8 * ROWB);
+        for (int j = 0; j < BJ; ++j) {
+            const bool real = (GB % NW == 0) || (wave + NW * j < GB);
+            async_copy16(real ? wtile + woff[j] + kt * BK : zero, real ? b + j * NW * RPI * ROWB : dummy);
+        }
     };
 
     f32x16 acc[MI][NI];
@@ -143,23 +157,29 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
     const int frow = lane & 31, fh = lane >> 5;
     int a_off[MI], b_off[NI], a_swz[MI], b_swz[NI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) { const int rr = wm * (BM / WM) + i * 32 + frow; a_off[i] = rr * ROWB; a_swz[i] = (rr >> 1) & 7; }
+    for (int i = 0; i < MI; ++i) { const int rr = wm * (BM / WM) + i * 32 + frow; a_off[i] = rr * ROWB; a_swz[i] = (rr / RPB) % SPR; }
 #pragma unroll
-    for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + frow; b_off[j] = rr * ROWB; b_swz[j] = (rr >> 1) & 7; }
+    for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + frow; b_off[j] = BM * ROWB + rr * ROWB; b_swz[j] = (rr / RPB) % SPR; }
 
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                 // tile kt has landed (DMA drained before the barrier), buffer (kt+1)&1 is free
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* a = sA + (kt & 1) * BM * ROWB;
-        const char* b = sB + (kt & 1) * BN * ROWB;
 #pragma unroll
-        for (int ks = 0; ks < CG_BK / 16; ++ks) {
+    for (int t = 0; t < DIST; ++t)
+        if (t < nk) issue(t, t);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed; the (up to DIST-1) younger tiles may stay in flight
+        const int younger = min(nk, kt + DIST) - (kt + 1);
+        if (DIST >= 3 && younger == 2) dma_wait<2 * PER_TILE>();
+        else if (DIST >= 2 && younger >= 1) dma_wait<(DIST >= 2 ? PER_TILE : 0)>();
+        else dma_wait<0>();
+        block_barrier();                 // everyone's share of tile kt landed; buffer (kt-1)%STAGES is free
+        if (kt + DIST < nk) issue(kt + DIST, (kt + DIST) % STAGES);
+        const char* st = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
             u32x4 fa[MI], fb[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const u32x4*>(a + a_off[i] + (((ks * 2 + fh) ^ a_swz[i]) << 4));
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + a_off[i] + (((ks * 2 + fh) ^ a_swz[i]) << 4));
 #pragma unroll
-            for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b + b_off[j] + (((ks * 2 + fh) ^ b_swz[j]) << 4));
+            for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const u32x4*>(st + b_off[j] + (((ks * 2 + fh) ^ b_swz[j]) << 4));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -183,10 +203,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
     // rows of one tile fall into at most two row-vector groups when rowvec_div >= BM (always true on the
     // UNet path: rowvec_div = frames*H*W); otherwise divide per element.
     const bool two_groups = p.rowvec_div >= BM;
-    const int out_cols = p.geglu ? BN / 2 : BN;          // tile width in output columns
     const int n_cols = p.geglu ? (p.n_out >> 1) : p.n_out;
-    const int chunks_per_row = out_cols >> 3;
-    const int col0 = tile_n * out_cols;
 
     // per-column terms are the same in every pass: hoist them
     float bcol[NI], rv0[NI], rv1[NI];
@@ -203,6 +220,30 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
             rv1[j] = (float)rowvec[(int64_t)min(g0 + 1, gmax) * p.n_out + nbj[j]];
         }
     }
+
+    // row-major read-back of one staged pass, CPR = 16-byte chunks per output row (compile-time: no divides)
+    auto read_back = [&](int ps, auto cpr_tag) {
+        constexpr int CPR = decltype(cpr_tag)::value;
+        const int col0 = tile_n * CPR * 8;
+        for (int c = tid; c < PROWS * CPR; c += THREADS) {
+            const int rl = c / CPR, ch = c - rl * CPR;
+            const int m = m_tile + (rl >> 5) * (BM / WM) + ps * 32 + (rl & 31), n = col0 + ch * 8;
+            if (m >= M || n >= n_cols) continue;
+            Pack8<T> v; v.raw = *reinterpret_cast<const u32x4*>(sE + rl * LDE + ch * 8);
+            if (CPR * 8 != BN) {                          // GEGLU: value half | gate half of the tile
+                Pack8<T> gt; gt.raw = *reinterpret_cast<const u32x4*>(sE + rl * LDE + CPR * 8 + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.e[e] = (T)((float)v.e[e] * gelu_erf_f((float)gt.e[e]));
+            }
+            if (resid || p.out_scale != 1.0f) {
+                Pack8<T> rs; rs.raw = u32x4{0u, 0u, 0u, 0u};
+                if (resid) rs.raw = *reinterpret_cast<const u32x4*>(resid + (int64_t)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.e[e] = (T)(((float)v.e[e] + (float)rs.e[e]) * p.out_scale);
+            }
+            *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + n) = v.raw;
+        }
+    };
 
 #pragma unroll
     for (int ps = 0; ps < MI; ++ps) {
@@ -222,25 +263,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaCon
             }
         }
         __syncthreads();
-        // row-major read-back, 16 B per lane: GEGLU pairing, + residual, * scale, store
-        for (int c = tid; c < PROWS * chunks_per_row; c += THREADS) {
-            const int rl = c / chunks_per_row, ch = c - rl * chunks_per_row;
-            const int m = m_tile + (rl >> 5) * (BM / WM) + ps * 32 + (rl & 31), n = col0 + ch * 8;
-            if (m >= M || n >= n_cols) continue;
-            Pack8<T> v; v.raw = *reinterpret_cast<const u32x4*>(sE + rl * LDE + ch * 8);
-            if (p.geglu) {
-                Pack8<T> gt; gt.raw = *reinterpret_cast<const u32x4*>(sE + rl * LDE + out_cols + ch * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v.e[e] = (T)((float)v.e[e] * gelu_erf_f((float)gt.e[e]));
-            }
-            if (resid || p.out_scale != 1.0f) {
-                Pack8<T> rs; rs.raw = u32x4{0u, 0u, 0u, 0u};
-                if (resid) rs.raw = *reinterpret_cast<const u32x4*>(resid + (int64_t)m * p.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v.e[e] = (T)(((float)v.e[e] + (float)rs.e[e]) * p.out_scale);
-            }
-            *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + n) = v.raw;
-        }
+        if (p.geglu) read_back(ps, IntTag<BN / 16>());
+        else read_back(ps, IntTag<BN / 8>());
     }
 }
 

@@ -35,3 +35,11 @@ __device__ __forceinline__ void async_copy16(const void* gsrc, void* lds_wave_ba
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+
+// Counted wait on this wave's outstanding vector-memory operations (LDS-DMA included): returns once at
+// most N are still in flight, i.e. everything issued before the N youngest has landed.
+template <int N>
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Workgroup barrier WITHOUT the implicit vmcnt(0) drain of __syncthreads(); the "memory" clobber keeps the
+// compiler from moving LDS / DMA accesses across it.
+__device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "memory"); }

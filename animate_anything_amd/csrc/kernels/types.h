@@ -19,3 +19,7 @@ union Pack8 {
     u32x4 raw;
     T e[8];
 };
+
+// compile-time integer carried as a type (lets a generic lambda take a constant)
+template <int N>
+struct IntTag { static constexpr int value = N; };

@@ -27,7 +27,9 @@ TRACE = None
 # (outside hipGraph capture) every tile shape of the library's table that fits is timed on the real
 # operands and the fastest index is remembered for that signature (descriptor field `tile`).
 AUTOTUNE = True
-TILE_TABLE = ((128, 64), (128, 128), (192, 256), (256, 256), (256, 320), (192, 320))   # mirrors csrc/aa_api_impl.h
+# (BM, BN, BK, stages) - mirrors the table in csrc/aa_api_impl.h
+TILE_TABLE = ((128, 64, 64, 2), (128, 128, 64, 2), (192, 256, 64, 2), (256, 256, 64, 2), (256, 320, 64, 2), (192, 320, 64, 2),
+              (256, 320, 32, 4), (256, 256, 32, 4), (128, 128, 32, 4), (128, 64, 32, 4), (192, 320, 32, 4))
 _tile_cache = {}
 
 
@@ -36,7 +38,7 @@ def _tile_candidates(d):
     if not dma:
         return []
     out = []
-    for i, (bm, bn) in enumerate(TILE_TABLE):
+    for i, (bm, bn, _bk, _st) in enumerate(TILE_TABLE):
         if d.n_pad % bn:
             continue
         if d.geglu and bn != 2 * d.geglu:
@@ -139,7 +141,7 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
         w4 = torch.nn.functional.pad(w4, (0, cpad - cin))
     k = kh * kw * cpad
     k_order = 0
-    if kh * kw > 1 and cpad % 64 == 0:
+    if kh * kw > 1 and cpad % 64 == 0 and n % 8 == 0:      # (only shapes that take the LDS-DMA path)
         # multi-tap filter: chunk-major K so the 9 (3) taps of one 64-channel slab are consecutive K steps
         w4 = w4.reshape(n, kh * kw, cpad // 64, 64).permute(0, 2, 1, 3)
         k_order = 1

@@ -49,11 +49,11 @@ def sweep(name, fn, flops, n_pad, geglu=0):
     report(name + " [auto]", timeit(fn), flops=flops)
     if not a.cfg_sweep:
         return
-    for i, (bm, bn) in enumerate(CFGS):
+    for i, (bm, bn, bk, st) in enumerate(CFGS):
         if n_pad % bn or (geglu and bn != 2 * geglu):
             continue
         lib.aa_set_tile_override(i)
-        report(f"{name} [{bm}x{bn}]", timeit(fn), flops=flops)
+        report(f"{name} [{bm}x{bn} k{bk} s{st}]", timeit(fn), flops=flops)
     lib.aa_set_tile_override(-1)
 
 

@@ -194,3 +194,7 @@ inline const void* zero_page() { static const u32x4 z[4] = {}; return z; }
 inline void async_copy16(const void* gsrc, void* lds_wave_base) {
     std::memcpy(static_cast<char*>(lds_wave_base) + (emu::linear_tid() & 63) * 16, gsrc, 16);
 }
+
+template <int N>
+inline void dma_wait() {}                       // the emulator's DMA is synchronous
+inline void block_barrier() { emu::block_barrier(); }
