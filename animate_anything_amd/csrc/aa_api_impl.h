@@ -49,6 +49,9 @@ static const CgCfg kCgCfgs[] = {
     {128, 128, 2, 2, 32, 4, 2, 0.95f},    // 8
     {128, 64, 2, 2, 32, 4, 3, 0.80f},     // 9
     {192, 320, 3, 2, 32, 4, 1, 1.10f},    // 10
+    {128, 320, 2, 2, 32, 2, 2, 1.10f},    // 11 two independent 4-wave workgroups per CU (phases de-synchronise)
+    {128, 256, 2, 2, 32, 2, 2, 1.05f},    // 12
+    {128, 256, 2, 2, 64, 2, 1, 1.00f},    // 13
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -76,11 +79,11 @@ static int cg_choose(const AaConvGemm& d, int M) {
     return best;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES>
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU>
 static void cg_launch_dma(const AaConvGemm& d, int M, void* stream) {
     const int tiles_n = d.n_pad / BN;
     const dim3 grid(((M + BM - 1) / BM) * tiles_n), block(64 * WM * WN);
-    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, M, tiles_n);
+    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES, PER_CU>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, M, tiles_n);
 }
 
 template <typename T>
@@ -92,17 +95,20 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
                      d.ldo % 8 == 0 && aligned16(d.out) && (!d.residual || (d.ldr % 8 == 0 && aligned16(d.residual)));
     if (dma) {
         switch (cg_choose(d, M)) {
-            case 0: cg_launch_dma<T, 128, 64, 2, 2, 64, 2>(d, M, stream); break;
-            case 1: cg_launch_dma<T, 128, 128, 2, 2, 64, 2>(d, M, stream); break;
-            case 2: cg_launch_dma<T, 192, 256, 3, 2, 64, 2>(d, M, stream); break;
-            case 3: cg_launch_dma<T, 256, 256, 4, 2, 64, 2>(d, M, stream); break;
-            case 4: cg_launch_dma<T, 256, 320, 4, 2, 64, 2>(d, M, stream); break;
-            case 5: cg_launch_dma<T, 192, 320, 3, 2, 64, 2>(d, M, stream); break;
-            case 6: cg_launch_dma<T, 256, 320, 4, 2, 32, 4>(d, M, stream); break;
-            case 7: cg_launch_dma<T, 256, 256, 4, 2, 32, 4>(d, M, stream); break;
-            case 8: cg_launch_dma<T, 128, 128, 2, 2, 32, 4>(d, M, stream); break;
-            case 9: cg_launch_dma<T, 128, 64, 2, 2, 32, 4>(d, M, stream); break;
-            case 10: cg_launch_dma<T, 192, 320, 3, 2, 32, 4>(d, M, stream); break;
+            case 0: cg_launch_dma<T, 128, 64, 2, 2, 64, 2, 3>(d, M, stream); break;
+            case 1: cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2>(d, M, stream); break;
+            case 2: cg_launch_dma<T, 192, 256, 3, 2, 64, 2, 1>(d, M, stream); break;
+            case 3: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1>(d, M, stream); break;
+            case 4: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1>(d, M, stream); break;
+            case 5: cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1>(d, M, stream); break;
+            case 6: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1>(d, M, stream); break;
+            case 7: cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1>(d, M, stream); break;
+            case 8: cg_launch_dma<T, 128, 128, 2, 2, 32, 4, 2>(d, M, stream); break;
+            case 9: cg_launch_dma<T, 128, 64, 2, 2, 32, 4, 3>(d, M, stream); break;
+            case 10: cg_launch_dma<T, 192, 320, 3, 2, 32, 4, 1>(d, M, stream); break;
+            case 11: cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2>(d, M, stream); break;
+            case 12: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2>(d, M, stream); break;
+            case 13: cg_launch_dma<T, 128, 256, 2, 2, 64, 2, 1>(d, M, stream); break;
             default: return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
         }
         return finish("conv_gemm");

@@ -132,12 +132,15 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p)
                         if (key >= p.kv_len) sacc[kb][e] = -1.0e30f;
                     }
             }
-            float mloc = sacc[0][0];
+            // row max: four independent chains, then a tree (a single 32-long fmax chain is pure latency)
+            float mx[4];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int c = 0; c < 4; ++c) mx[c] = fmaxf(sacc[c >> 1][8 * (c & 1)], sacc[c >> 1][8 * (c & 1) + 1]);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[kb][e]);
-            mloc = fmaxf(mloc, wave_shfl_xor(mloc, 32));
+            for (int e = 2; e < 8; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) mx[c] = fmaxf(mx[c], sacc[c >> 1][8 * (c & 1) + e]);
+            const float mloc = wave_max_halves(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
             const float m_new = fmaxf(m_run, mloc);
             if (wave_any(m_new > m_run)) {              // some row's max moved: rescale the accumulators
                 const float alpha = exp2f((m_run - m_new) * sl2e);
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p)
                 m_run = m_new;
             }
             const float mc = m_run * sl2e;
-            float psum = 0.0f;
+            float ps4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             u32x4 pf[4];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -157,11 +160,12 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float pe = exp2f(sacc[kb][8 * c + e] * sl2e - mc);
-                        psum += pe;
+                        ps4[2 * kb + c] += pe;
                         pk.e[e] = (T)pe;
                     }
                     pf[2 * kb + c] = pk.raw;
                 }
+            const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
             l_run += psum;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
@@ -180,7 +184,7 @@ __global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p)
     }
 
     if (wave_active) {
-        const float l_tot = l_run + wave_shfl_xor(l_run, 32);
+        const float l_tot = wave_sum_halves(l_run);
         const float inv = 1.0f / l_tot;
         const int q = q0 + ql;
         if (q < p.q_len) {

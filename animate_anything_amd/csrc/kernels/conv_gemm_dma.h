@@ -31,8 +31,9 @@ __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages)
     return operands > staging ? operands : staging;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES>
-__global__ void __launch_bounds__(64 * WM * WN) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n) {
+// PER_CU = workgroups meant to be co-resident on a CU (register budget: 512 / (PER_CU * waves per SIMD)).
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU>
+__global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n) {
     constexpr int NW = WM * WN;
     constexpr int THREADS = 64 * NW;
     constexpr int MI = BM / WM / 32;     // 32-row accumulator blocks per wave

@@ -23,6 +23,18 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16
 __device__ __forceinline__ float wave_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ bool wave_any(bool pred) { return __any((int)pred) != 0; }
+// Combine a value with the one held by the lane 32 positions away (the other half-wave) with ONE
+// v_permlane32_swap (VALU, no LDS crossbar): after swapping (x, x) every lane holds {own, other}.
+__device__ __forceinline__ float wave_max_halves(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float wave_sum_halves(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
 
 // 64 zero bytes in device memory: what halo / tail lanes of an LDS-DMA tile load read instead of an activation.
 __device__ __attribute__((aligned(64))) u32x4 aa_zero_page_[4];

@@ -157,6 +157,9 @@ inline float wave_shfl(float v, int src) {
     return out;
 }
 
+inline float wave_max_halves(float x) { return std::fmax(x, wave_shfl_xor(x, 32)); }
+inline float wave_sum_halves(float x) { return x + wave_shfl_xor(x, 32); }
+
 inline bool wave_any(bool pred) {
     bool out = false;
     emu::wave_collective(&pred, [&](const std::vector<const void*>& s) {
