@@ -52,6 +52,8 @@ static const CgCfg kCgCfgs[] = {
     {128, 320, 2, 2, 32, 2, 2, 1.10f},    // 11 two independent 4-wave workgroups per CU (phases de-synchronise)
     {128, 256, 2, 2, 32, 2, 2, 1.05f},    // 12
     {128, 256, 2, 2, 64, 2, 1, 1.00f},    // 13
+    {256, 320, 4, 2, 64, 2, 1, 1.30f},    // 14 staggered wave groups (half a K step apart)
+    {256, 256, 4, 2, 64, 2, 1, 1.30f},    // 15 staggered
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -79,11 +81,11 @@ static int cg_choose(const AaConvGemm& d, int M) {
     return best;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU>
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER = false>
 static void cg_launch_dma(const AaConvGemm& d, int M, void* stream) {
     const int tiles_n = d.n_pad / BN;
     const dim3 grid(((M + BM - 1) / BM) * tiles_n), block(64 * WM * WN);
-    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES, PER_CU>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, M, tiles_n);
+    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES, PER_CU, STAGGER>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, M, tiles_n);
 }
 
 template <typename T>
@@ -109,6 +111,8 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
             case 11: cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2>(d, M, stream); break;
             case 12: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2>(d, M, stream); break;
             case 13: cg_launch_dma<T, 128, 256, 2, 2, 64, 2, 1>(d, M, stream); break;
+            case 14: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, true>(d, M, stream); break;
+            case 15: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, true>(d, M, stream); break;
             default: return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
         }
         return finish("conv_gemm");

@@ -32,7 +32,7 @@ __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages)
 }
 
 // PER_CU = workgroups meant to be co-resident on a CU (register budget: 512 / (PER_CU * waves per SIMD)).
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU>
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER>
 __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n) {
     constexpr int NW = WM * WN;
     constexpr int THREADS = 64 * NW;
@@ -162,18 +162,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 #pragma unroll
     for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + frow; b_off[j] = BM * ROWB + rr * ROWB; b_swz[j] = (rr / RPB) % SPR; }
 
-#pragma unroll
-    for (int t = 0; t < DIST; ++t)
-        if (t < nk) issue(t, t);
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed; the (up to DIST-1) younger tiles may stay in flight
-        const int younger = min(nk, kt + DIST) - (kt + 1);
-        if (DIST >= 3 && younger == 2) dma_wait<2 * PER_TILE>();
-        else if (DIST >= 2 && younger >= 1) dma_wait<(DIST >= 2 ? PER_TILE : 0)>();
-        else dma_wait<0>();
-        block_barrier();                 // everyone's share of tile kt landed; buffer (kt-1)%STAGES is free
-        if (kt + DIST < nk) issue(kt + DIST, (kt + DIST) % STAGES);
-        const char* st = smem + (kt % STAGES) * STAGE_BYTES;
+    auto compute = [&](int buf) {
+        const char* st = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             u32x4 fa[MI], fb[NI];
@@ -185,6 +175,42 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    if constexpr (STAGGER) {
+        // Two wave groups (first / second wave of every SIMD) run half a K step apart: while one group
+        // multiplies tile kt the other only issues / waits for DMA, so the matrix pipe never sees both waves
+        // parked at the same barrier.  Two barriers per K step, two LDS buffers:
+        //   interval 2k  : both issue their share of tile kt+1 -> buffer (kt+1)&1 (its last reader, the late
+        //                  group's multiply of tile kt-1, finished before the previous barrier); EARLY multiplies kt
+        //   interval 2k+1: LATE multiplies tile kt; both drain their own DMA share before the closing barrier.
+        static_assert(!STAGGER || (STAGES == 2 && NW == 8), "stagger needs 8 waves and a 2-buffer ring");
+        const bool late = wave >= NW / 2;
+        issue(0, 0);
+        dma_wait<0>();
+        block_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+            if (!late) compute(kt & 1);
+            block_barrier();
+            if (late) compute(kt & 1);
+            dma_wait<0>();
+            block_barrier();
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIST; ++t)
+            if (t < nk) issue(t, t);
+        for (int kt = 0; kt < nk; ++kt) {
+            // tile kt must have landed; the (up to DIST-1) younger tiles may stay in flight
+            const int younger = min(nk, kt + DIST) - (kt + 1);
+            if (DIST >= 3 && younger == 2) dma_wait<2 * PER_TILE>();
+            else if (DIST >= 2 && younger >= 1) dma_wait<(DIST >= 2 ? PER_TILE : 0)>();
+            else dma_wait<0>();
+            block_barrier();                 // everyone's share of tile kt landed; buffer (kt-1)%STAGES is free
+            if (kt + DIST < nk) issue(kt + DIST, (kt + DIST) % STAGES);
+            compute(kt % STAGES);
         }
     }
 

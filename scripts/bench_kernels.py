@@ -53,7 +53,7 @@ def sweep(name, fn, flops, n_pad, geglu=0):
         if n_pad % bn or (geglu and bn != 2 * geglu):
             continue
         lib.aa_set_tile_override(i)
-        report(f"{name} [{bm}x{bn} k{bk} s{st}]", timeit(fn), flops=flops)
+        report(f"{name} [{i}:{bm}x{bn} k{bk} s{st}]", timeit(fn), flops=flops)
     lib.aa_set_tile_override(-1)
 
 
