@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     constexpr int PER_TILE = AJ + BJ;                    // every wave issues exactly this many per tile
     constexpr int DIST = STAGES - 1;                     // tiles in flight ahead of the multiply
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr bool FRAG_ASM = (MI * NI * 16 + 2 * (MI + NI) * 4) <= 184;   // accumulators + two fragment sets fit beside the rest
     static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % RPI == 0 && BN % RPI == 0, "tile shape");
     static_assert(BK == 64 || BK == 32, "K step");
     static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * PER_TILE <= 63, "pipeline depth");
@@ -162,19 +163,51 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 #pragma unroll
     for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + frow; b_off[j] = BM * ROWB + rr * ROWB; b_swz[j] = (rr / RPB) % SPR; }
 
+    // Fragment reads.  FRAG_ASM: two register sets, the ds_reads of sub-step ks+1 are hand-issued before the
+    // MFMAs of sub-step ks and waited with a counted lgkmcnt (LDS returns in order: "at most MI+NI outstanding"
+    // == the older set has landed), so LDS latency hides under the matrix pipe.  Otherwise plain C++ loads
+    // (hipcc keeps ONE set and waits lgkmcnt(0) each sub-step) - for shapes whose accumulators leave no room.
+    auto frag_ptr_a = [&](const char* st, int ks, int i) { return st + a_off[i] + (((ks * 2 + fh) ^ a_swz[i]) << 4); };
+    auto frag_ptr_b = [&](const char* st, int ks, int j) { return st + b_off[j] + (((ks * 2 + fh) ^ b_swz[j]) << 4); };
     auto compute = [&](int buf) {
         const char* st = smem + buf * STAGE_BYTES;
+        constexpr int KS = BK / 16;
+        if constexpr (FRAG_ASM) {
+            u32x4 fa[2][MI], fb[2][NI];
+            auto issue_frags = [&](int ks, int set) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            u32x4 fa[MI], fb[NI];
+                for (int i = 0; i < MI; ++i) lds_read16_async(fa[set][i], frag_ptr_a(st, ks, i));
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + a_off[i] + (((ks * 2 + fh) ^ a_swz[i]) << 4));
+                for (int j = 0; j < NI; ++j) lds_read16_async(fb[set][j], frag_ptr_b(st, ks, j));
+            };
+            issue_frags(0, 0);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const u32x4*>(st + b_off[j] + (((ks * 2 + fh) ^ b_swz[j]) << 4));
+            for (int ks = 0; ks < KS; ++ks) {
+                const int set = ks & 1;
+                if (ks + 1 < KS) { issue_frags(ks + 1, set ^ 1); lds_wait<MI + NI>(fa[set][0]); }
+                else lds_wait<0>(fa[set][0]);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 1; i < MI; ++i) lds_pin(fa[set][i]);
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < NI; ++j) lds_pin(fb[set][j]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fa[set][i], fb[set][j], acc[i][j]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4 fa[MI], fb[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const u32x4*>(frag_ptr_a(st, ks, i));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const u32x4*>(frag_ptr_b(st, ks, j));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fa[i], fb[j], acc[i][j]);
+            }
         }
     };
 

@@ -55,3 +55,26 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" 
 // Workgroup barrier WITHOUT the implicit vmcnt(0) drain of __syncthreads(); the "memory" clobber keeps the
 // compiler from moving LDS / DMA accesses across it.
 __device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// Scheduling directive for one k sub-step of a fragment-double-buffered MFMA loop: emit the NR ds_reads
+// (next sub-step's fragments) first, then the NM MFMAs of this sub-step - hipcc otherwise sinks the reads
+// next to their first use and waits lgkmcnt(0) right behind them (LDS latency exposed every sub-step).
+template <int NR, int NM>
+__device__ __forceinline__ void sched_reads_then_mfma() {
+    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);   // DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);   // MFMA
+}
+
+// Hand-issued LDS fragment read: `dst` is written asynchronously (lgkmcnt); hipcc neither counts it nor waits
+// for it, so every consumer must sit behind lds_wait<N>() / lds_pin() naming the register (cdna guide 5.7).
+// Lets a k sub-step's ds_reads stay in flight under the previous sub-step's MFMAs with a COUNTED wait -
+// compiled C++ loads are re-materialised into one register set and waited with lgkmcnt(0) every sub-step.
+__device__ __forceinline__ void lds_read16_async(u32x4& dst, const void* lds_ptr) {
+    const unsigned addr = (unsigned)(unsigned long long)lds_ptr;        // low 32 bits of a flat LDS pointer = LDS offset
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+// Wait until at most N LDS operations are outstanding; `x` becomes available to consumers here.
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N)); }
+// Order the consumers of `x` behind the preceding lds_wait (no instruction emitted).
+__device__ __forceinline__ void lds_pin(u32x4& x) { asm volatile("" : "+v"(x)); }

@@ -201,3 +201,11 @@ inline void async_copy16(const void* gsrc, void* lds_wave_base) {
 template <int N>
 inline void dma_wait() {}                       // the emulator's DMA is synchronous
 inline void block_barrier() { emu::block_barrier(); }
+
+template <int NR, int NM>
+inline void sched_reads_then_mfma() {}
+
+inline void lds_read16_async(u32x4& dst, const void* lds_ptr) { dst = *reinterpret_cast<const u32x4*>(lds_ptr); }
+template <int N>
+inline void lds_wait(u32x4&) {}
+inline void lds_pin(u32x4&) {}
