@@ -242,8 +242,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             else if (DIST >= 2 && younger >= 1) dma_wait<(DIST >= 2 ? PER_TILE : 0)>();
             else dma_wait<0>();
             block_barrier();                 // everyone's share of tile kt landed; buffer (kt-1)%STAGES is free
-            if (kt + DIST < nk) issue(kt + DIST, (kt + DIST) % STAGES);
-            compute(kt % STAGES);
+            if (kt + DIST < nk && !(p.debug & 1)) issue(kt + DIST, (kt + DIST) % STAGES);
+            if (!(p.debug & 2)) compute(kt % STAGES);
         }
     }
 

@@ -27,6 +27,7 @@ TRACE = None
 # (outside hipGraph capture) every tile shape of the library's table that fits is timed on the real
 # operands and the fastest index is remembered for that signature (descriptor field `tile`).
 AUTOTUNE = True
+DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
 # (BM, BN, BK, stages) - mirrors the table in csrc/aa_api_impl.h
 TILE_TABLE = ((128, 64, 64, 2), (128, 128, 64, 2), (192, 256, 64, 2), (256, 256, 64, 2), (256, 320, 64, 2), (192, 320, 64, 2),
               (256, 320, 32, 4), (256, 256, 32, 4), (128, 128, 32, 4), (128, 64, 32, 4), (192, 320, 32, 4),
@@ -238,6 +239,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.act, d.geglu, d.bias_per_row = act, int(pw.geglu), int(bias_per_row)
     d.dtype, d.out_dtype, d.out_scale = _DT[x0.dtype], _DT[odt], out_scale
     d.k_order = pw.k_order
+    d.debug = DEBUG_ABLATE
     d.tile = -1
     if AUTOTUNE and x0.is_cuda:
         key = (d.dtype, g.n_img, g.h_in, g.w_in, d.h_virt, d.w_virt, g.h_out, g.w_out, g.stride, pw.kh, pw.kw, c0, c1,
