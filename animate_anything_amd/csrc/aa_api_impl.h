@@ -82,10 +82,34 @@ static int cg_choose(const AaConvGemm& d, int M) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER = false>
-static void cg_launch_dma(const AaConvGemm& d, int M, void* stream) {
+static void cg_launch_dma(const AaConvGemm& d, int m_begin, int m_end, void* stream) {
     const int tiles_n = d.n_pad / BN;
-    const dim3 grid(((M + BM - 1) / BM) * tiles_n), block(64 * WM * WN);
-    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES, PER_CU, STAGGER>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, M, tiles_n);
+    const dim3 grid(((m_end - m_begin + BM - 1) / BM) * tiles_n), block(64 * WM * WN);
+    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES, PER_CU, STAGGER>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, m_end, tiles_n, m_begin);
+}
+
+template <typename T>
+static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, void* stream) {
+    switch (cfg) {
+        case 0: cg_launch_dma<T, 128, 64, 2, 2, 64, 2, 3>(d, m_begin, m_end, stream); break;
+        case 1: cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2>(d, m_begin, m_end, stream); break;
+        case 2: cg_launch_dma<T, 192, 256, 3, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
+        case 3: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
+        case 4: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
+        case 5: cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
+        case 6: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1>(d, m_begin, m_end, stream); break;
+        case 7: cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1>(d, m_begin, m_end, stream); break;
+        case 8: cg_launch_dma<T, 128, 128, 2, 2, 32, 4, 2>(d, m_begin, m_end, stream); break;
+        case 9: cg_launch_dma<T, 128, 64, 2, 2, 32, 4, 3>(d, m_begin, m_end, stream); break;
+        case 10: cg_launch_dma<T, 192, 320, 3, 2, 32, 4, 1>(d, m_begin, m_end, stream); break;
+        case 11: cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2>(d, m_begin, m_end, stream); break;
+        case 12: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2>(d, m_begin, m_end, stream); break;
+        case 13: cg_launch_dma<T, 128, 256, 2, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
+        case 14: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, stream); break;
+        case 15: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, stream); break;
+        default: return false;
+    }
+    return true;
 }
 
 template <typename T>
@@ -96,24 +120,33 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
     const bool dma = (d.c0 + d.c1) % 64 == 0 && d.c0 % 64 == 0 && d.out_dtype == d.dtype && n_cols % 8 == 0 &&
                      d.ldo % 8 == 0 && aligned16(d.out) && (!d.residual || (d.ldr % 8 == 0 && aligned16(d.residual)));
     if (dma) {
-        switch (cg_choose(d, M)) {
-            case 0: cg_launch_dma<T, 128, 64, 2, 2, 64, 2, 3>(d, M, stream); break;
-            case 1: cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2>(d, M, stream); break;
-            case 2: cg_launch_dma<T, 192, 256, 3, 2, 64, 2, 1>(d, M, stream); break;
-            case 3: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1>(d, M, stream); break;
-            case 4: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1>(d, M, stream); break;
-            case 5: cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1>(d, M, stream); break;
-            case 6: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1>(d, M, stream); break;
-            case 7: cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1>(d, M, stream); break;
-            case 8: cg_launch_dma<T, 128, 128, 2, 2, 32, 4, 2>(d, M, stream); break;
-            case 9: cg_launch_dma<T, 128, 64, 2, 2, 32, 4, 3>(d, M, stream); break;
-            case 10: cg_launch_dma<T, 192, 320, 3, 2, 32, 4, 1>(d, M, stream); break;
-            case 11: cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2>(d, M, stream); break;
-            case 12: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2>(d, M, stream); break;
-            case 13: cg_launch_dma<T, 128, 256, 2, 2, 64, 2, 1>(d, M, stream); break;
-            case 14: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, true>(d, M, stream); break;
-            case 15: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, true>(d, M, stream); break;
-            default: return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
+        const int cfg = cg_choose(d, M);
+        if (cfg < 0) return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
+        // One-workgroup-per-CU tiles run in lock-step rounds of 256; a sparsely filled last round wastes most of
+        // the chip.  Split it off: full rounds with the big tile, the remaining rows with a small (2-3 per CU) tile.
+        const CgCfg& c = kCgCfgs[cfg];
+        int m_main = M;
+        if (c.per_cu == 1) {
+            const int tiles_n = d.n_pad / c.bn;
+            const int tiles_m = (M + c.bm - 1) / c.bm;
+            const int cus = (d.debug & 4) ? 2 : 256;          // debug bit 4: pretend a 2-CU chip (exercises the split in tests)
+            const int rounds = tiles_m * tiles_n / cus;
+            const int rem = tiles_m * tiles_n - rounds * cus;
+            if (rounds >= 1 && rem > 0 && rem * 8 < cus * 5) m_main = (rounds * cus / tiles_n) * c.bm;
+        }
+        if (m_main > M) m_main = M;
+        cg_launch_cfg<T>(cfg, d, 0, m_main, stream);
+        if (m_main < M) {
+            AaConvGemm tail = d;
+            tail.tile = -1;
+            int tcfg = -1;
+            const int small[2] = {1, 0};
+            for (int k = 0; k < 2 && tcfg < 0; ++k) {
+                const CgCfg& t = kCgCfgs[small[k]];
+                if (d.n_pad % t.bn == 0 && (!d.geglu || t.bn == 2 * d.geglu)) tcfg = small[k];
+            }
+            if (tcfg < 0) cg_launch_cfg<T>(cfg, d, m_main, M, stream);      // no small tile fits (wide GEGLU): big tile again
+            else cg_launch_cfg<T>(tcfg, tail, m_main, M, stream);
         }
         return finish("conv_gemm");
     }

@@ -33,7 +33,9 @@ __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages)
 
 // PER_CU = workgroups meant to be co-resident on a CU (register budget: 512 / (PER_CU * waves per SIMD)).
 template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER>
-__global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n) {
+__global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n, const int m_begin) {
+    // rows [m_begin, M) of the output are tiled by this launch (a launch may cover only part of the rows:
+    // the host splits off a sparsely filled last round of big tiles and runs it with small tiles)
     constexpr int NW = WM * WN;
     constexpr int THREADS = 64 * NW;
     constexpr int MI = BM / WM / 32;     // 32-row accumulator blocks per wave
@@ -70,6 +72,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const int ctot = p.c0 + p.c1;
     const int nk = p.k_pad / BK;
     const bool resize = (p.h_virt != p.h_in) || (p.w_virt != p.w_in);
+    const bool linear = p.kh * p.kw == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 && !resize;
 
     // ---- DMA geometry: this lane feeds LDS rows ((wave + NW*j)*RPI + lane/SPR), 16-byte position lane%SPR ----
     const int lrow = lane / SPR, lpos = lane % SPR;
@@ -79,15 +82,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int rr = (wave + NW * j) * RPI + lrow;
-        const int m = tile_m * BM + rr;
+        const int m = m_begin + tile_m * BM + rr;
         row_ok[j] = m < M && rr < BM;
         const int mm = row_ok[j] ? m : 0;
-        const int x = mm % p.w_out;
-        const int t = mm / p.w_out;
-        const int y = t % p.h_out;
-        row_img[j] = t / p.h_out;
-        row_iy[j] = y * p.stride - p.pad_h;
-        row_ix[j] = x * p.stride - p.pad_w;
+        if (linear) {                    // 1x1 / nn.Linear: the row IS the pixel, no (img, y, x) decomposition
+            row_img[j] = 0; row_iy[j] = 0; row_ix[j] = mm;
+        } else {
+            const int x = mm % p.w_out;
+            const int t = mm / p.w_out;
+            const int y = t % p.h_out;
+            row_img[j] = t / p.h_out;
+            row_iy[j] = y * p.stride - p.pad_h;
+            row_ix[j] = x * p.stride - p.pad_w;
+        }
         kslot[j] = lpos ^ ((rr / RPB) % SPR);
         aoff[j] = -1;
     }
@@ -119,6 +126,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const int iy = row_iy[j] + dy, ix = row_ix[j] + dx;
+                if (linear) { pixel[j] = (tap_ok && row_ok[j]) ? ix : -1; continue; }
                 const bool ok = tap_ok && row_ok[j] && (unsigned)iy < (unsigned)p.h_virt && (unsigned)ix < (unsigned)p.w_virt;
                 int sy = iy, sx = ix;
                 if (resize) { sy = (iy * p.h_in) / p.h_virt; sx = (ix * p.w_in) / p.w_virt; }
@@ -257,7 +265,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const T* resid = reinterpret_cast<const T*>(p.residual);
     T* out = reinterpret_cast<T*>(p.out);
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-    const int m_tile = tile_m * BM;
+    const int m_tile = m_begin + tile_m * BM;
     const int g0 = m_tile / p.rowvec_div;
     const int g_edge = (g0 + 1) * p.rowvec_div;
     // rows of one tile fall into at most two row-vector groups when rowvec_div >= BM (always true on the

@@ -85,7 +85,8 @@ typedef struct AaConvGemm {
     float out_scale;
     int32_t k_order;       /* 0: packed K is (tap, channel); 1: (64-channel chunk, tap, channel) - LDS-DMA path only */
     int32_t debug;         /* 0 in production.  Ablation bits for profiling: 1 = skip operand DMA after the first tile,
-                              2 = skip the MFMA phase (results are garbage) */
+                              2 = skip the MFMA phase (results are garbage); 4 = size the
+                              round-splitting heuristic for a 2-CU chip (exercises it on small test shapes) */
     int32_t tile;          /* -1: library picks the tile shape; >= 0: index into the tile table (autotuning) */
 } AaConvGemm;
 

@@ -209,3 +209,6 @@ inline void lds_read16_async(u32x4& dst, const void* lds_ptr) { dst = *reinterpr
 template <int N>
 inline void lds_wait(u32x4&) {}
 inline void lds_pin(u32x4&) {}
+
+using std::fabs;
+inline float fabsf_(float x) { return std::fabs(x); }

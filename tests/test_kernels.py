@@ -269,3 +269,21 @@ def test_geglu_wide_tiles(backend, D):
     assert pw.geglu == 160
     h = x.float() @ w.float().t() + b.float()
     close(ops.conv_gemm(x, pw, ops.linear_geom(M)), h[:, :D] * F.gelu(h[:, D:]))
+
+
+def test_sparse_last_round_is_split_to_small_tiles(backend):
+    """Big-tile launches hand a sparsely filled last round of tiles to a small-tile launch (m_begin path)."""
+    from animate_anything_amd import _lib
+    n, h, w, cin, N = 3, 15, 16, 64, 320              # M = 720 rows: 2 full 256-row tiles + 208 left over
+    x, wt, b = rnd(n, cin, h, w, seed=71), rnd(N, cin, 3, 3, scale=0.05, seed=72), rnd(N, seed=73)
+    g = ops.conv3x3_geom(n, h, w)
+    res = rnd(g.rows, N, seed=74)
+    lib = _lib.get()
+    lib.aa_set_tile_override(4)
+    ops.DEBUG_ABLATE = 4
+    try:
+        y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res)
+    finally:
+        lib.aa_set_tile_override(-1)
+        ops.DEBUG_ABLATE = 0
+    close(y, nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1)).half().float() + res.float())
