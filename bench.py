@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--gemm-breakdown", default="", help="write a per-shape table of the contraction launches of one step")
     return p.parse_args()
 
 
@@ -179,6 +180,29 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         gemm_ms = e0.elapsed_time(e1) / reps
+        if a.gemm_breakdown:
+            from collections import defaultdict
+            groups = defaultdict(lambda: [0, 0.0, 0.0, -1])
+            for d, _ in trace:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for _ in range(3):
+                    lib.aa_conv_gemm(C.byref(d), stream)
+                ev1.record()
+                ev1.synchronize()
+                key = (d.n_img * d.h_out * d.w_out, d.kh * d.kw * (d.c0 + d.c1), d.n_out, f"{d.kh}x{d.kw}s{d.stride}",
+                       "geglu" if d.geglu else "", "up" if d.h_virt != d.h_in else "")
+                g_ = groups[key]
+                g_[0] += 1
+                g_[1] += ev0.elapsed_time(ev1) / 3
+                g_[2] += 2.0 * key[0] * key[1] * key[2]
+                g_[3] = d.tile
+            with open(a.gemm_breakdown, "w") as f:
+                f.write("M K N kind flags | launches total_ms TFLOP/s tile share\n")
+                tot = sum(v[1] for v in groups.values())
+                for key, v in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+                    f.write(f"{key[0]:7d} {key[1]:6d} {key[2]:6d} {key[3]:6s} {key[4]:5s}{key[5]:3s} | {v[0]:3d} {v[1]:8.3f} "
+                            f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} {v[3]:3d} {v[1] / tot * 100:5.1f}%\n")
         ach = flops / (gemm_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
