@@ -54,6 +54,8 @@ static const CgCfg kCgCfgs[] = {
     {128, 256, 2, 2, 64, 2, 1, 1.00f},    // 13
     {256, 320, 4, 2, 64, 2, 1, 1.30f},    // 14 staggered wave groups (half a K step apart)
     {256, 256, 4, 2, 64, 2, 1, 1.30f},    // 15 staggered
+    {128, 128, 2, 2, 32, 2, 3, 0.90f},    // 16 three small-LDS workgroups per CU
+    {128, 64, 2, 2, 32, 2, 4, 0.78f},     // 17 four per CU
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -107,6 +109,8 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 13: cg_launch_dma<T, 128, 256, 2, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
         case 14: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, stream); break;
         case 15: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, stream); break;
+        case 16: cg_launch_dma<T, 128, 128, 2, 2, 32, 2, 3>(d, m_begin, m_end, stream); break;
+        case 17: cg_launch_dma<T, 128, 64, 2, 2, 32, 2, 4>(d, m_begin, m_end, stream); break;
         default: return false;
     }
     return true;

@@ -34,7 +34,7 @@ __device__ __forceinline__ const T* attn_row(const AaAttnOperand& x, int o, int 
 __device__ __forceinline__ int vt_swz(int d) { return ((d >> 3) + 2 * (d & 7)) & 7; }
 
 template <typename T, int NW>
-__global__ void __launch_bounds__(64 * NW) attention_kernel(const AaAttention p) {
+__global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(const AaAttention p) {
     constexpr int THREADS = 64 * NW;
     constexpr int SLOTS = (AT_KT * 8) / THREADS;     // 16-byte K (and V) slots staged per thread
     T* lds = reinterpret_cast<T*>(dyn_smem());
