@@ -56,6 +56,9 @@ static const CgCfg kCgCfgs[] = {
     {256, 256, 4, 2, 64, 2, 1, 1.30f},    // 15 staggered
     {128, 128, 2, 2, 32, 2, 3, 0.90f},    // 16 three small-LDS workgroups per CU
     {128, 64, 2, 2, 32, 2, 4, 0.78f},     // 17 four per CU
+    {64, 128, 2, 2, 32, 2, 4, 0.70f},     // 18 short tiles for the small-M levels (more workgroups)
+    {64, 64, 2, 2, 32, 2, 6, 0.60f},      // 19
+    {64, 256, 2, 2, 32, 2, 3, 0.80f},     // 20
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -111,6 +114,9 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 15: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, stream); break;
         case 16: cg_launch_dma<T, 128, 128, 2, 2, 32, 2, 3>(d, m_begin, m_end, stream); break;
         case 17: cg_launch_dma<T, 128, 64, 2, 2, 32, 2, 4>(d, m_begin, m_end, stream); break;
+        case 18: cg_launch_dma<T, 64, 128, 2, 2, 32, 2, 4>(d, m_begin, m_end, stream); break;
+        case 19: cg_launch_dma<T, 64, 64, 2, 2, 32, 2, 6>(d, m_begin, m_end, stream); break;
+        case 20: cg_launch_dma<T, 64, 256, 2, 2, 32, 2, 3>(d, m_begin, m_end, stream); break;
         default: return false;
     }
     return true;

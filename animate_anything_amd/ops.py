@@ -31,7 +31,7 @@ DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
 # (BM, BN, BK, stages) - mirrors the table in csrc/aa_api_impl.h
 TILE_TABLE = ((128, 64, 64, 2), (128, 128, 64, 2), (192, 256, 64, 2), (256, 256, 64, 2), (256, 320, 64, 2), (192, 320, 64, 2),
               (256, 320, 32, 4), (256, 256, 32, 4), (128, 128, 32, 4), (128, 64, 32, 4), (192, 320, 32, 4),
-              (128, 320, 32, 2), (128, 256, 32, 2), (128, 256, 64, 2), (256, 320, 64, 2), (256, 256, 64, 2), (128, 128, 32, 2), (128, 64, 32, 2))
+              (128, 320, 32, 2), (128, 256, 32, 2), (128, 256, 64, 2), (256, 320, 64, 2), (256, 256, 64, 2), (128, 128, 32, 2), (128, 64, 32, 2), (64, 128, 32, 2), (64, 64, 32, 2), (64, 256, 32, 2))
 _tile_cache = {}
 
 
