@@ -26,7 +26,7 @@ class AaConvGemm(C.Structure):
         ("n_out", C.c_int32), ("n_pad", C.c_int32), ("k_pad", C.c_int32),
         ("rowvec_div", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
         ("act", C.c_int32), ("geglu", C.c_int32), ("bias_per_row", C.c_int32),
-        ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("out_scale", C.c_float), ("k_order", C.c_int32), ("debug", C.c_int32), ("tile", C.c_int32),
+        ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("k_order", C.c_int32), ("debug", C.c_int32), ("tile", C.c_int32),
     ]
 
 
@@ -62,7 +62,7 @@ class AaDpmStep(C.Structure):
     ]
 
 
-SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm", "aa_groupnorm_workspace", "aa_groupnorm",
+SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_groupnorm_workspace", "aa_groupnorm",
            "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step")
 
 DEFAULT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaa_mi355.so")
@@ -82,6 +82,8 @@ def bind(path: str) -> C.CDLL:
     lib.aa_set_tile_override.argtypes = [C.c_int]
     lib.aa_set_tile_override.restype = None
     lib.aa_conv_gemm.argtypes = [C.POINTER(AaConvGemm), C.c_void_p]
+    lib.aa_conv_gemm_workspace.argtypes = [C.POINTER(AaConvGemm)]
+    lib.aa_conv_gemm_workspace.restype = C.c_size_t
     lib.aa_groupnorm_workspace.argtypes = [C.POINTER(AaGroupNorm)]
     lib.aa_groupnorm_workspace.restype = C.c_size_t
     lib.aa_groupnorm.argtypes = [C.POINTER(AaGroupNorm), C.c_void_p, C.c_size_t, C.c_void_p]
@@ -91,7 +93,7 @@ def bind(path: str) -> C.CDLL:
     lib.aa_softmax_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.aa_cfg_dpm_step.argtypes = [C.POINTER(AaDpmStep), C.c_void_p]
     for s in SYMBOLS[3:]:
-        if s != "aa_groupnorm_workspace":
+        if s not in ("aa_groupnorm_workspace", "aa_conv_gemm_workspace"):
             getattr(lib, s).restype = C.c_int
     return lib
 

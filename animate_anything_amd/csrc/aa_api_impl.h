@@ -86,37 +86,57 @@ static int cg_choose(const AaConvGemm& d, int M) {
     return best;
 }
 
+// Split-K factor: few output tiles but a long K loop (the small-M levels) leave most CUs idle behind a serial
+// chain of K steps; spread the K range over up to 8 workgroups per tile (fp32 partials + a reduce launch).
+static int cg_splits(const AaConvGemm& d, int M, const CgCfg& c) {
+    if (d.geglu) return 1;
+    const int tiles = ((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
+    const int slots = 256 * c.per_cu;
+    const int nk = d.k_pad / c.bk;
+    if (tiles * 2 > slots || nk < 32) return 1;
+    int s = slots / tiles;
+    if (s > 8) s = 8;
+    if (s > nk / 8) s = nk / 8;
+    return s < 1 ? 1 : s;
+}
+
+static bool cg_dma_ok(const AaConvGemm& d) {
+    const int n_cols = d.geglu ? d.n_out / 2 : d.n_out;
+    return (d.c0 + d.c1) % 64 == 0 && d.c0 % 64 == 0 && d.out_dtype == d.dtype && n_cols % 8 == 0 &&
+           d.ldo % 8 == 0 && aligned16(d.out) && (!d.residual || (d.ldr % 8 == 0 && aligned16(d.residual)));
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER = false>
-static void cg_launch_dma(const AaConvGemm& d, int m_begin, int m_end, void* stream) {
+static void cg_launch_dma(const AaConvGemm& d, int m_begin, int m_end, int splits, void* stream) {
     const int tiles_n = d.n_pad / BN;
-    const dim3 grid(((m_end - m_begin + BM - 1) / BM) * tiles_n), block(64 * WM * WN);
-    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES, PER_CU, STAGGER>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, m_end, tiles_n, m_begin);
+    const dim3 grid(((m_end - m_begin + BM - 1) / BM) * tiles_n, splits), block(64 * WM * WN);
+    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES, PER_CU, STAGGER>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, m_end, tiles_n, m_begin, splits);
 }
 
 template <typename T>
-static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, void* stream) {
+static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, void* stream, int splits = 1) {
     switch (cfg) {
-        case 0: cg_launch_dma<T, 128, 64, 2, 2, 64, 2, 3>(d, m_begin, m_end, stream); break;
-        case 1: cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2>(d, m_begin, m_end, stream); break;
-        case 2: cg_launch_dma<T, 192, 256, 3, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
-        case 3: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
-        case 4: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
-        case 5: cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
-        case 6: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1>(d, m_begin, m_end, stream); break;
-        case 7: cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1>(d, m_begin, m_end, stream); break;
-        case 8: cg_launch_dma<T, 128, 128, 2, 2, 32, 4, 2>(d, m_begin, m_end, stream); break;
-        case 9: cg_launch_dma<T, 128, 64, 2, 2, 32, 4, 3>(d, m_begin, m_end, stream); break;
-        case 10: cg_launch_dma<T, 192, 320, 3, 2, 32, 4, 1>(d, m_begin, m_end, stream); break;
-        case 11: cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2>(d, m_begin, m_end, stream); break;
-        case 12: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2>(d, m_begin, m_end, stream); break;
-        case 13: cg_launch_dma<T, 128, 256, 2, 2, 64, 2, 1>(d, m_begin, m_end, stream); break;
-        case 14: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, stream); break;
-        case 15: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, stream); break;
-        case 16: cg_launch_dma<T, 128, 128, 2, 2, 32, 2, 3>(d, m_begin, m_end, stream); break;
-        case 17: cg_launch_dma<T, 128, 64, 2, 2, 32, 2, 4>(d, m_begin, m_end, stream); break;
-        case 18: cg_launch_dma<T, 64, 128, 2, 2, 32, 2, 4>(d, m_begin, m_end, stream); break;
-        case 19: cg_launch_dma<T, 64, 64, 2, 2, 32, 2, 6>(d, m_begin, m_end, stream); break;
-        case 20: cg_launch_dma<T, 64, 256, 2, 2, 32, 2, 3>(d, m_begin, m_end, stream); break;
+        case 0: cg_launch_dma<T, 128, 64, 2, 2, 64, 2, 3>(d, m_begin, m_end, splits, stream); break;
+        case 1: cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2>(d, m_begin, m_end, splits, stream); break;
+        case 2: cg_launch_dma<T, 192, 256, 3, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
+        case 3: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
+        case 4: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
+        case 5: cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
+        case 6: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1>(d, m_begin, m_end, splits, stream); break;
+        case 7: cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1>(d, m_begin, m_end, splits, stream); break;
+        case 8: cg_launch_dma<T, 128, 128, 2, 2, 32, 4, 2>(d, m_begin, m_end, splits, stream); break;
+        case 9: cg_launch_dma<T, 128, 64, 2, 2, 32, 4, 3>(d, m_begin, m_end, splits, stream); break;
+        case 10: cg_launch_dma<T, 192, 320, 3, 2, 32, 4, 1>(d, m_begin, m_end, splits, stream); break;
+        case 11: cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2>(d, m_begin, m_end, splits, stream); break;
+        case 12: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2>(d, m_begin, m_end, splits, stream); break;
+        case 13: cg_launch_dma<T, 128, 256, 2, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
+        case 14: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, splits, stream); break;
+        case 15: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, splits, stream); break;
+        case 16: cg_launch_dma<T, 128, 128, 2, 2, 32, 2, 3>(d, m_begin, m_end, splits, stream); break;
+        case 17: cg_launch_dma<T, 128, 64, 2, 2, 32, 2, 4>(d, m_begin, m_end, splits, stream); break;
+        case 18: cg_launch_dma<T, 64, 128, 2, 2, 32, 2, 4>(d, m_begin, m_end, splits, stream); break;
+        case 19: cg_launch_dma<T, 64, 64, 2, 2, 32, 2, 6>(d, m_begin, m_end, splits, stream); break;
+        case 20: cg_launch_dma<T, 64, 256, 2, 2, 32, 2, 3>(d, m_begin, m_end, splits, stream); break;
         default: return false;
     }
     return true;
@@ -126,12 +146,17 @@ template <typename T>
 static int conv_gemm_t(const AaConvGemm& d, void* stream) {
     const int M = (int)((int64_t)d.n_img * d.h_out * d.w_out);
     // LDS-DMA fast path: K tiles never straddle a filter tap / concat source, output rows are 16-byte chunks
-    const int n_cols = d.geglu ? d.n_out / 2 : d.n_out;
-    const bool dma = (d.c0 + d.c1) % 64 == 0 && d.c0 % 64 == 0 && d.out_dtype == d.dtype && n_cols % 8 == 0 &&
-                     d.ldo % 8 == 0 && aligned16(d.out) && (!d.residual || (d.ldr % 8 == 0 && aligned16(d.residual)));
-    if (dma) {
+    if (cg_dma_ok(d)) {
         const int cfg = cg_choose(d, M);
         if (cfg < 0) return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
+        const int splits = cg_splits(d, M, kCgCfgs[cfg]);
+        if (splits > 1 && d.workspace && d.workspace_bytes >= (int64_t)splits * M * d.n_pad * 4) {
+            cg_launch_cfg<T>(cfg, d, 0, M, stream, splits);
+            int64_t blocks = ((int64_t)M * (d.n_out / 8) + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            AA_LAUNCH((splitk_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, d, M, splits);
+            return finish("conv_gemm");
+        }
         // One-workgroup-per-CU tiles run in lock-step rounds of 256; a sparsely filled last round wastes most of
         // the chip.  Split it off: full rounds with the big tile, the remaining rows with a small (2-3 per CU) tile.
         const CgCfg& c = kCgCfgs[cfg];
@@ -211,6 +236,16 @@ extern "C" {
 int aa_version(void) { return AA_VERSION; }
 void aa_set_tile_override(int cfg) { aa::g_tile_override = cfg < 0 ? -1 : cfg; }
 const char* aa_last_error(void) { return aa::g_err; }
+
+size_t aa_conv_gemm_workspace(const AaConvGemm* d) {
+    using namespace aa;
+    if (!d || !cg_dma_ok(*d)) return 0;
+    const int M = (int)((int64_t)d->n_img * d->h_out * d->w_out);
+    const int cfg = cg_choose(*d, M);
+    if (cfg < 0) return 0;
+    const int s = cg_splits(*d, M, kCgCfgs[cfg]);
+    return s > 1 ? (size_t)s * M * d->n_pad * 4 : 0;
+}
 
 int aa_conv_gemm(const AaConvGemm* d, void* stream) {
     using namespace aa;

@@ -33,7 +33,7 @@ __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages)
 
 // PER_CU = workgroups meant to be co-resident on a CU (register budget: 512 / (PER_CU * waves per SIMD)).
 template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER>
-__global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n, const int m_begin) {
+__global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n, const int m_begin, const int k_splits) {
     // rows [m_begin, M) of the output are tiled by this launch (a launch may cover only part of the rows:
     // the host splits off a sparsely filled last round of big tiles and runs it with small tiles)
     constexpr int NW = WM * WN;
@@ -70,7 +70,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const int tile_n = logical - tile_m * tiles_n;
 
     const int ctot = p.c0 + p.c1;
-    const int nk = p.k_pad / BK;
+    // split-K: blockIdx.y owns K steps [kbase, kbase + nk) and leaves raw fp32 partial sums in the workspace
+    const int nk_all = p.k_pad / BK;
+    const int k_per = (nk_all + k_splits - 1) / k_splits;
+    const int kbase = blockIdx.y * k_per;
+    const int nk = max(0, min(k_per, nk_all - kbase));
     const bool resize = (p.h_virt != p.h_in) || (p.w_virt != p.w_in);
     const bool linear = p.kh * p.kw == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 && !resize;
 
@@ -114,7 +118,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         // K order (wave-uniform scalars): tap-major (tap, channel) or, for multi-tap filters packed
         // chunk-major, (64-channel chunk, tap, channel) - consecutive K steps then re-read the same
         // activation slab shifted by one tap, which keeps it L2-resident across the 9 taps.
-        const int k0 = kt * BK;
+        const int k0 = (kbase + kt) * BK;
         int tap, cb;
         if (p.k_order) { const int taps = p.kh * p.kw; const int unit = k0 >> 6; const int chunk = unit / taps;
                          tap = unit - chunk * taps; cb = chunk * 64 + (k0 & 63); }
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const bool real = (GB % NW == 0) || (wave + NW * j < GB);
-            async_copy16(real ? wtile + woff[j] + kt * BK : zero, real ? b + j * NW * RPI * ROWB : dummy);
+            async_copy16(real ? wtile + woff[j] + (kbase + kt) * BK : zero, real ? b + j * NW * RPI * ROWB : dummy);
         }
     };
 
@@ -255,6 +259,23 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         }
     }
 
+    if (k_splits > 1) {
+        // partial sums straight from the accumulator layout (col = lane&31, 4-row groups): ws[split][m][n] fp32
+        float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)blockIdx.y * M * p.n_pad;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = tile_n * BN + wn * (BN / WN) + j * 32 + (lane & 31);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m_begin + tile_m * BM + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (m < M) ws[(int64_t)m * p.n_pad + n] = acc[i][j][e];
+                }
+            }
+        return;
+    }
+
     // ---- epilogue: pass i stages accumulator block-row i of EVERY wave (WM*32 tile rows) through an LDS
     // tile [WM*32][BN+8] of storage dtype; acc[i] is dead after pass i, so register pressure only falls ----
     constexpr int LDE = BN + 8;
@@ -336,4 +357,43 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     }
 }
 
+}  // namespace aa
+
+namespace aa {
+// Split-K finish: sum the fp32 partials of `splits` K ranges and apply the usual epilogue (bias, row vector,
+// activation, residual, scale); one 16-byte output chunk per thread.
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const AaConvGemm p, const int M, const int splits) {
+    const int cpr = p.n_out >> 3;
+    const int64_t total = (int64_t)M * cpr;
+    const float* ws = reinterpret_cast<const float*>(p.workspace);
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    const T* rowvec = reinterpret_cast<const T*>(p.rowvec);
+    const T* resid = reinterpret_cast<const T*>(p.residual);
+    T* out = reinterpret_cast<T*>(p.out);
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < total; c += (int64_t)gridDim.x * 256) {
+        const int m = (int)(c / cpr), n = (int)(c - (int64_t)m * cpr) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        for (int sp = 0; sp < splits; ++sp) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(ws + ((int64_t)sp * M + m) * p.n_pad + n);
+            const f32x4 a = src[0], b = src[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+        }
+        Pack8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            if (bias) x += (float)bias[p.bias_per_row ? m : n + e];
+            if (rowvec) x += (float)rowvec[(int64_t)(m / p.rowvec_div) * p.n_out + n + e];
+            if (p.act == AA_ACT_SILU) x = silu_f(x);
+            x = (float)(T)x;                                       // same rounding point as the fused epilogue
+            if (resid) x += (float)resid[(int64_t)m * p.ldr + n + e];
+            o.e[e] = (T)(x * p.out_scale);
+        }
+        *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + n) = o.raw;
+    }
+}
 }  // namespace aa

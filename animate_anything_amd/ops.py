@@ -248,9 +248,14 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
         if tile is None and not torch.cuda.is_current_stream_capturing():
             tile = _autotune(lib, d, _stream(x0), key)
         d.tile = -1 if tile is None else tile
+    ws = None
+    need = lib.aa_conv_gemm_workspace(C.byref(d))        # split-K scratch for few-tile / long-K calls
+    if need:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=x0.device)
+        d.workspace, d.workspace_bytes = _ptr(ws), need
     _run(lib.aa_conv_gemm, C.byref(d), _stream(x0))
     if TRACE is not None:
-        TRACE.append((d, (x0, x1, pw, b, rowvec, residual, out)))
+        TRACE.append((d, (x0, x1, pw, b, rowvec, residual, out, ws)))
     return out
 
 

@@ -83,6 +83,8 @@ typedef struct AaConvGemm {
     int32_t dtype;         /* AA_F16 | AA_BF16: activations + weights */
     int32_t out_dtype;     /* AA_F16 | AA_BF16 (== dtype) or AA_F32 */
     float out_scale;
+    void* workspace;       /* optional fp32 scratch for split-K (aa_conv_gemm_workspace bytes); NULL = never split */
+    int64_t workspace_bytes;
     int32_t k_order;       /* 0: packed K is (tap, channel); 1: (64-channel chunk, tap, channel) - LDS-DMA path only */
     int32_t debug;         /* 0 in production.  Ablation bits for profiling: 1 = skip operand DMA after the first tile,
                               2 = skip the MFMA phase (results are garbage); 4 = size the
@@ -90,6 +92,9 @@ typedef struct AaConvGemm {
     int32_t tile;          /* -1: library picks the tile shape; >= 0: index into the tile table (autotuning) */
 } AaConvGemm;
 
+/* Bytes of fp32 scratch with which aa_conv_gemm would split the K loop of this call over several workgroups
+ * (few output tiles, long K: the small-M levels); 0 when it would not. */
+size_t aa_conv_gemm_workspace(const AaConvGemm* d);
 int aa_conv_gemm(const AaConvGemm* d, void* stream);
 
 /* Tuning / test aid: force tile shape `cfg` (index into the table in csrc/aa_api_impl.h) for every

@@ -287,3 +287,16 @@ def test_sparse_last_round_is_split_to_small_tiles(backend):
         lib.aa_set_tile_override(-1)
         ops.DEBUG_ABLATE = 0
     close(y, nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1)).half().float() + res.float())
+
+
+def test_split_k_long_k_few_tiles(backend):
+    """Few output tiles + long K: the K loop is split over workgroups (fp32 partials + reduce launch)."""
+    M, K, N = 150, 2048, 128
+    x, w, b, r = rnd(M, K, scale=0.5, seed=81), rnd(N, K, scale=0.05, seed=82), rnd(N, seed=83), rnd(M, N, seed=84)
+    y = ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M), residual=r, act=AA_ACT_SILU, out_scale=0.5)
+    close(y, (F.silu(x.float() @ w.float().t() + b.float()).half().float() + r.float()) * 0.5)
+    n, h, w_, cin, cout = 1, 6, 7, 256, 64           # 3x3 conv, K = 2304 (36 K steps), chunk-major weights
+    xi, wt, bb = rnd(n, cin, h, w_, seed=85), rnd(cout, cin, 3, 3, scale=0.03, seed=86), rnd(cout, seed=87)
+    temb = rnd(n, cout, seed=88)
+    y = ops.conv_gemm(nhwc(xi), ops.pack_weight(wt, bb), ops.conv3x3_geom(n, h, w_), rowvec=temb, rowvec_div=h * w_)
+    close(y, nhwc(F.conv2d(xi.float(), wt.float(), bb.float(), padding=1) + temb.float()[:, :, None, None]))
