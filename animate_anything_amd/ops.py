@@ -28,11 +28,26 @@ TRACE = None
 # operands and the fastest index is remembered for that signature (descriptor field `tile`).
 AUTOTUNE = True
 DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
+GEGLU_GRAN = 0        # 0: automatic (160 when the inner width allows, else 64); 64 / 160 force a packing
 # (BM, BN, BK, stages) - mirrors the table in csrc/aa_api_impl.h
 TILE_TABLE = ((128, 64, 64, 2), (128, 128, 64, 2), (192, 256, 64, 2), (256, 256, 64, 2), (256, 320, 64, 2), (192, 320, 64, 2),
               (256, 320, 32, 4), (256, 256, 32, 4), (128, 128, 32, 4), (128, 64, 32, 4), (192, 320, 32, 4),
               (128, 320, 32, 2), (128, 256, 32, 2), (128, 256, 64, 2), (256, 320, 64, 2), (256, 256, 64, 2), (128, 128, 32, 2), (128, 64, 32, 2), (64, 128, 32, 2), (64, 64, 32, 2), (64, 256, 32, 2))
 _tile_cache = {}
+
+
+def save_tile_cache(path):
+    """Persist the autotuned tile choices (json) so a later process can skip the tuning launches."""
+    import json
+    with open(path, "w") as f:
+        json.dump([[list(k), v] for k, v in _tile_cache.items()], f)
+
+
+def load_tile_cache(path):
+    import json
+    with open(path) as f:
+        for k, v in json.load(f):
+            _tile_cache[tuple(k)] = v
 
 
 def _tile_candidates(d):
@@ -58,8 +73,9 @@ def _autotune(lib, d, stream, key):
             d.tile = c
             if lib.aa_conv_gemm(C.byref(d), stream) != 0:
                 continue
+            lib.aa_conv_gemm(C.byref(d), stream)
             e0.record()
-            for _ in range(3):
+            for _ in range(4):
                 lib.aa_conv_gemm(C.byref(d), stream)
             e1.record()
             e1.synchronize()
@@ -151,7 +167,7 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     b = None if bias is None else bias.detach()
     if geglu:
         d = n // 2
-        gran = 160 if d % 160 == 0 else 64          # half the width of the tile shape that will own the pair
+        gran = GEGLU_GRAN or (160 if d % 160 == 0 else 64)   # half the width of the tile shape that will own the pair
         assert d % gran == 0, "GEGLU inner width must be a multiple of 64"
         val = torch.arange(d, device=w.device).reshape(d // gran, 1, gran)
         src = torch.cat([val, val + d], dim=1).reshape(-1)

@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--tile-cache", default="", help="json file with autotuned tile choices: loaded if present, written after warm-up")
     p.add_argument("--gemm-breakdown", default="", help="write a per-shape table of the contraction launches of one step")
     return p.parse_args()
 
@@ -116,6 +117,8 @@ def main():
     ts = [int(t) for t in pipe.scheduler.timesteps][:total]
     if not a.no_graph:
         unet.enable_graph()
+    if a.tile_cache and os.path.exists(a.tile_cache):
+        ops.load_tile_cache(a.tile_cache)
 
     def run(tsteps, x):
         return pipe.denoise(x, embeds, inp["cond"], inp["mask"], [3.0], tsteps, 9.0)
@@ -127,6 +130,8 @@ def main():
 
     with torch.no_grad():
         x = run(ts[: a.warmup], inp["latents"]) if a.warmup else inp["latents"]
+        if a.tile_cache and rank == 0:
+            ops.save_tile_cache(a.tile_cache)
         barrier()
         t0 = time.perf_counter()
         x = run(ts[a.warmup:], x)
