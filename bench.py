@@ -209,8 +209,15 @@ def main():
                     f.write(f"{key[0]:7d} {key[1]:6d} {key[2]:6d} {key[3]:6s} {key[4]:5s}{key[5]:3s} | {v[0]:3d} {v[1]:8.3f} "
                             f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} {v[3]:3d} {v[1] / tot * 100:5.1f}%\n")
         ach = flops / (gemm_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the dominant kernel: PMC numbers (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+        # separate rocprofv3 passes, scripts/pmc_traffic.sh) committed under profiles/ - bench.py cannot run the
+        # profiler on itself, so `traffic` is the last committed measurement of the same command (null if absent)
+        traffic, tpath = None, os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("conv_gemm_dma_kernel", {}).get("hbm_bytes_per_launch")
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                           "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_traffic_pmc.json)",
                            "kernel": "aa::conv_gemm_kernel (implicit-GEMM conv/linear, all instances)",
                            "launches_per_step": len(trace), "avg_launch_us": round(gemm_ms * 1e3 / len(trace), 2),
                            "flop_per_step_in_kernel": flops, "kernel_ms_per_step": round(gemm_ms, 3),
