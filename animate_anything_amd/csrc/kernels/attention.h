@@ -62,19 +62,30 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
         }
     }
 
+    // per-slot K / V source pointers of tile 0, advanced by one tile (64 keys) per fetch: no 64-bit row
+    // arithmetic in the loop
     u32x4 rk[SLOTS], rv[SLOTS];
+    const T* kptr[SLOTS];
+    const T* vptr[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int sl = tid + s * THREADS;
+        kptr[s] = attn_row<T>(p.k, o, i, sl >> 3, head) + (sl & 7) * 8;
+        vptr[s] = attn_row<T>(p.v, o, i, sl >> 3, head) + (sl & 7) * 8;
+    }
+    const int64_t k_step = (int64_t)AT_KT * p.k.pos_stride * p.k.ld, v_step = (int64_t)AT_KT * p.v.pos_stride * p.v.ld;
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int sl = tid + s * THREADS;
-            const int key = kt * AT_KT + (sl >> 3), dseg = sl & 7;
-            const bool ok = key < p.kv_len;
+            const bool ok = kt * AT_KT + (sl >> 3) < p.kv_len;
             u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
             if (ok) {
-                a = *reinterpret_cast<const u32x4*>(attn_row<T>(p.k, o, i, key, head) + dseg * 8);
-                b = *reinterpret_cast<const u32x4*>(attn_row<T>(p.v, o, i, key, head) + dseg * 8);
+                a = *reinterpret_cast<const u32x4*>(kptr[s]);
+                b = *reinterpret_cast<const u32x4*>(vptr[s]);
             }
             rk[s] = a; rv[s] = b;
+            kptr[s] += k_step; vptr[s] += v_step;
         }
     };
     auto stash = [&](int buf) {
@@ -143,7 +154,7 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
             const float mloc = wave_max_halves(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
             const float m_new = fmaxf(m_run, mloc);
             if (wave_any(m_new > m_run)) {              // some row's max moved: rescale the accumulators
-                const float alpha = exp2f((m_run - m_new) * sl2e);
+                const float alpha = fast_exp2((m_run - m_new) * sl2e);
                 l_run *= alpha;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
@@ -159,7 +170,7 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
                     Pack8<T> pk;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float pe = exp2f(sacc[kb][8 * c + e] * sl2e - mc);
+                        const float pe = fast_exp2(sacc[kb][8 * c + e] * sl2e - mc);
                         ps4[2 * kb + c] += pe;
                         pk.e[e] = (T)pe;
                     }

@@ -22,6 +22,9 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16
 
 __device__ __forceinline__ float wave_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, src, 64); }
+// bare v_exp_f32 (2^x): no denormal-range fix-up sequence around it - callers only pass x <= 0 and are happy with
+// results that underflow to 0.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ bool wave_any(bool pred) { return __any((int)pred) != 0; }
 // Combine a value with the one held by the lane 32 positions away (the other half-wave) with ONE
 // v_permlane32_swap (VALU, no LDS crossbar): after swapping (x, x) every lane holds {own, other}.

@@ -157,6 +157,7 @@ inline float wave_shfl(float v, int src) {
     return out;
 }
 
+inline float fast_exp2(float x) { return std::exp2(x); }
 inline float wave_max_halves(float x) { return std::fmax(x, wave_shfl_xor(x, 32)); }
 inline float wave_sum_halves(float x) { return x + wave_shfl_xor(x, 32); }
 
