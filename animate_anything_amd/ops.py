@@ -73,13 +73,17 @@ def _autotune(lib, d, stream, key):
             d.tile = c
             if lib.aa_conv_gemm(C.byref(d), stream) != 0:
                 continue
-            lib.aa_conv_gemm(C.byref(d), stream)
             e0.record()
-            for _ in range(4):
+            lib.aa_conv_gemm(C.byref(d), stream)
+            e1.record()
+            e1.synchronize()
+            reps = min(40, max(4, int(1.5 / max(e0.elapsed_time(e1), 0.01))))     # ~1.5 ms of timed launches
+            e0.record()
+            for _ in range(reps):
                 lib.aa_conv_gemm(C.byref(d), stream)
             e1.record()
             e1.synchronize()
-            t = e0.elapsed_time(e1)
+            t = e0.elapsed_time(e1) / reps
             if best_t is None or t < best_t:
                 best, best_t = c, t
     _tile_cache[key] = best
