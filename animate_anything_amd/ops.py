@@ -73,17 +73,16 @@ def _autotune(lib, d, stream, key):
             d.tile = c
             if lib.aa_conv_gemm(C.byref(d), stream) != 0:
                 continue
-            e0.record()
-            lib.aa_conv_gemm(C.byref(d), stream)
-            e1.record()
-            e1.synchronize()
-            reps = min(40, max(4, int(1.5 / max(e0.elapsed_time(e1), 0.01))))     # ~1.5 ms of timed launches
-            e0.record()
-            for _ in range(reps):
+            # one launch per measurement, synchronised in between: back-to-back launches of one kernel overlap
+            # their tails, which hides exactly the last-round under-fill that a dependent chain of kernels pays
+            ts = []
+            for _ in range(5):
+                e0.record()
                 lib.aa_conv_gemm(C.byref(d), stream)
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1) / reps
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            t = sorted(ts)[1]
             if best_t is None or t < best_t:
                 best, best_t = c, t
     _tile_cache[key] = best
