@@ -202,12 +202,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
                 for (int i = 1; i < MI; ++i) lds_pin(fa[set][i]);
 #pragma unroll
                 for (int j = 0; j < NI; ++j) lds_pin(fb[set][j]);
-                wave_priority<1>();
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fa[set][i], fb[set][j], acc[i][j]);
-                wave_priority<0>();
             }
         } else {
 #pragma unroll

@@ -81,8 +81,3 @@ template <int N>
 __device__ __forceinline__ void lds_wait(u32x4& x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N)); }
 // Order the consumers of `x` behind the preceding lds_wait (no instruction emitted).
 __device__ __forceinline__ void lds_pin(u32x4& x) { asm volatile("" : "+v"(x)); }
-
-// Wave priority hint for the CU's instruction arbiter (T5): raised around MFMA clusters so co-resident waves that
-// are issuing loads / address arithmetic do not steal issue slots from the matrix pipe.
-template <int P>
-__device__ __forceinline__ void wave_priority() { __builtin_amdgcn_s_setprio(P); }

@@ -213,6 +213,3 @@ inline void lds_pin(u32x4&) {}
 
 using std::fabs;
 inline float fabsf_(float x) { return std::fabs(x); }
-
-template <int P>
-inline void wave_priority() {}
