@@ -160,8 +160,9 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
                 for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
                 m_run = m_new;
             }
-            const float mc = m_run * sl2e;
-            float ps4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float nmc = -m_run * sl2e;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 ps2[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};      // packed partial row sums
             u32x4 pf[4];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -169,14 +170,18 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
                 for (int c = 0; c < 2; ++c) {
                     Pack8<T> pk;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float pe = fast_exp2(sacc[kb][8 * c + e] * sl2e - mc);
-                        ps4[2 * kb + c] += pe;
-                        pk.e[e] = (T)pe;
+                    for (int e = 0; e < 8; e += 2) {
+                        f32x2 pe;
+                        pe[0] = fast_exp2(__builtin_fmaf(sacc[kb][8 * c + e], sl2e, nmc));       // one v_fma + one v_exp per score
+                        pe[1] = fast_exp2(__builtin_fmaf(sacc[kb][8 * c + e + 1], sl2e, nmc));
+                        ps2[2 * kb + c] += pe;
+                        pk.e[e] = (T)pe[0];
+                        pk.e[e + 1] = (T)pe[1];
                     }
                     pf[2 * kb + c] = pk.raw;
                 }
-            const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+            const f32x2 pst = (ps2[0] + ps2[1]) + (ps2[2] + ps2[3]);
+            const float psum = pst[0] + pst[1];
             l_run += psum;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
