@@ -149,7 +149,8 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
     if (cg_dma_ok(d)) {
         const int cfg = cg_choose(d, M);
         if (cfg < 0) return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
-        const int splits = cg_splits(d, M, kCgCfgs[cfg]);
+        const bool probe = (d.debug & 8) != 0;               // phase probe: the workspace holds time stamps, one plain launch
+        const int splits = probe ? 1 : cg_splits(d, M, kCgCfgs[cfg]);
         if (splits > 1 && d.workspace && d.workspace_bytes >= (int64_t)splits * M * d.n_pad * 4) {
             cg_launch_cfg<T>(cfg, d, 0, M, stream, splits);
             int64_t blocks = ((int64_t)M * (d.n_out / 8) + 255) / 256;
@@ -161,7 +162,7 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
         // the chip.  Split it off: full rounds with the big tile, the remaining rows with a small (2-3 per CU) tile.
         const CgCfg& c = kCgCfgs[cfg];
         int m_main = M;
-        if (c.per_cu == 1) {
+        if (c.per_cu == 1 && !probe) {
             const int tiles_n = d.n_pad / c.bn;
             const int tiles_m = (M + c.bm - 1) / c.bm;
             const int cus = (d.debug & 4) ? 2 : 256;          // debug bit 4: pretend a 2-CU chip (exercises the split in tests)

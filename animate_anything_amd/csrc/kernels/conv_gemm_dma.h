@@ -69,6 +69,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const int tile_m = logical / tiles_n;
     const int tile_n = logical - tile_m * tiles_n;
 
+    // debug bit 8 (phase probe): thread 0 leaves shader-clock stamps in workspace[bid][8]
+    auto stamp = [&](int slot) {
+        if ((p.debug & 8) && tid == 0) reinterpret_cast<long long*>(p.workspace)[(int64_t)blockIdx.x * 8 + slot] = clock_now();
+    };
+    stamp(0);
     const int ctot = p.c0 + p.c1;
     // split-K: blockIdx.y owns K steps [kbase, kbase + nk) and leaves raw fp32 partial sums in the workspace
     const int nk_all = p.k_pad / BK;
@@ -223,6 +228,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         }
     };
 
+    stamp(1);
     if constexpr (STAGGER) {
         // Two wave groups (first / second wave of every SIMD) run half a K step apart: while one group
         // multiplies tile kt the other only issues / waits for DMA, so the matrix pipe never sees both waves
@@ -259,6 +265,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         }
     }
 
+    stamp(2);
     if (k_splits > 1) {
         // partial sums straight from the accumulator layout (col = lane&31, 4-row groups): ws[split][m][n] fp32
         float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)blockIdx.y * M * p.n_pad;
@@ -352,9 +359,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             }
         }
         __syncthreads();
+        if (ps == 0) stamp(3);
         if (p.geglu) read_back(ps, IntTag<BN / 16>());
         else read_back(ps, IntTag<BN / 8>());
+        if (ps == 0) stamp(4);
     }
+    stamp(5);
 }
 
 }  // namespace aa

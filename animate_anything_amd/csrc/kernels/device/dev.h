@@ -39,6 +39,9 @@ __device__ __forceinline__ float wave_sum_halves(float x) {
     return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 
+// Shader-clock timestamp (s_memtime) for the phase probe (AaConvGemm.debug bit 8).
+__device__ __forceinline__ long long clock_now() { return (long long)__builtin_amdgcn_s_memtime(); }
+
 // 64 zero bytes in device memory: what halo / tail lanes of an LDS-DMA tile load read instead of an activation.
 __device__ __attribute__((aligned(64))) u32x4 aa_zero_page_[4];
 __device__ __forceinline__ const void* zero_page() { return aa_zero_page_; }

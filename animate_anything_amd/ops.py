@@ -27,6 +27,7 @@ TRACE = None
 # (outside hipGraph capture) every tile shape of the library's table that fits is timed on the real
 # operands and the fastest index is remembered for that signature (descriptor field `tile`).
 AUTOTUNE = True
+LAST_STAMPS = None
 DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
 GEGLU_GRAN = 0        # 0: automatic (160 when the inner width allows, else 64); 64 / 160 force a packing
 # (BM, BN, BK, stages) - mirrors the table in csrc/aa_api_impl.h
@@ -269,7 +270,11 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
         d.tile = -1 if tile is None else tile
     ws = None
     need = lib.aa_conv_gemm_workspace(C.byref(d))        # split-K scratch for few-tile / long-K calls
-    if need:
+    if DEBUG_ABLATE & 8:                                  # phase probe: [workgroup][8] shader-clock stamps
+        global LAST_STAMPS
+        ws = LAST_STAMPS = torch.zeros(1 << 16, 8, dtype=torch.int64, device=x0.device)
+        d.workspace, d.workspace_bytes = _ptr(ws), ws.numel() * 8
+    elif need:
         ws = torch.empty(need // 4, dtype=torch.float32, device=x0.device)
         d.workspace, d.workspace_bytes = _ptr(ws), need
     _run(lib.aa_conv_gemm, C.byref(d), _stream(x0))

@@ -224,6 +224,14 @@ class AutoencoderKL(nn.Module):
         model.load_state_dict(state)
         return model.to(torch_dtype) if torch_dtype is not None else model
 
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, self.config_name), "w") as f:
+            json.dump(dict(vars(self.config), _class_name="AutoencoderKL"), f, indent=2)
+        from safetensors.torch import save_file
+        save_file({k: v.contiguous().cpu() for k, v in self.state_dict().items()},
+                  os.path.join(path, "diffusion_pytorch_model.safetensors"))
+
     def _guard(self, x):
         if not x.is_cuda and not _lib.host_pointers_ok():
             raise RuntimeError("animate_anything_amd.AutoencoderKL runs on the GPU only (no CPU fallback)")

@@ -194,6 +194,7 @@ inline f32x16 emu_mfma_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
 inline f32x16 mfma_32x32x16(f16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<f16_t>(a, b, c); }
 inline f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<bf16_t>(a, b, c); }
 
+inline long long clock_now() { return 0; }
 inline const void* zero_page() { static const u32x4 z[4] = {}; return z; }
 inline void async_copy16(const void* gsrc, void* lds_wave_base) {
     std::memcpy(static_cast<char*>(lds_wave_base) + (emu::linear_tid() & 63) * 16, gsrc, 16);
