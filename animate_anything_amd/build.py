@@ -15,8 +15,13 @@ def _deps():
     return deps
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/aa_api.hip -> libaa_mi355.so (skipped when up to date). Returns the path."""
+PROBE_LIB = os.path.join(PKG, "libaa_mi355_probe.so")
+
+
+def build(force=False, verbose=False, probe=False):
+    """Compile csrc/aa_api.hip -> libaa_mi355.so (skipped when up to date). Returns the path.
+    probe=True builds the -DAA_PHASE_PROBE profiling variant (scripts/phase_probe.py) next to it."""
+    LIB = PROBE_LIB if probe else globals()["LIB"]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _deps()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -24,6 +29,8 @@ def build(force=False, verbose=False):
            "-I", os.path.join(CSRC, "kernels", "device"), "-I", os.path.join(CSRC, "kernels"), "-I", CSRC,
            "-I", os.path.join(ROOT, "include"),
            os.path.join(CSRC, "aa_api.hip"), "-o", LIB]
+    if probe:
+        cmd.insert(1, "-DAA_PHASE_PROBE")
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
@@ -32,4 +39,4 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     import sys
-    print(build(force=True, verbose="-v" in sys.argv))
+    print(build(force=True, verbose="-v" in sys.argv, probe="--probe" in sys.argv))

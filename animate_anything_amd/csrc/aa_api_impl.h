@@ -52,13 +52,15 @@ static const CgCfg kCgCfgs[] = {
     {128, 320, 2, 2, 32, 2, 2, 1.10f},    // 11 two independent 4-wave workgroups per CU (phases de-synchronise)
     {128, 256, 2, 2, 32, 2, 2, 1.05f},    // 12
     {128, 256, 2, 2, 64, 2, 1, 1.00f},    // 13
-    {256, 320, 4, 2, 64, 2, 1, 1.30f},    // 14 staggered wave groups (half a K step apart)
-    {256, 256, 4, 2, 64, 2, 1, 1.30f},    // 15 staggered
+    {256, 320, 4, 2, 64, 2, 1, 1.30f},    // 14 staggered: the second wave of every SIMD multiplies before it issues its DMA share
+    {256, 256, 4, 2, 64, 2, 1, 1.25f},    // 15 staggered
     {128, 128, 2, 2, 32, 2, 3, 0.90f},    // 16 three small-LDS workgroups per CU
     {128, 64, 2, 2, 32, 2, 4, 0.78f},     // 17 four per CU
     {64, 128, 2, 2, 32, 2, 4, 0.70f},     // 18 short tiles for the small-M levels (more workgroups)
     {64, 64, 2, 2, 32, 2, 6, 0.60f},      // 19
     {64, 256, 2, 2, 32, 2, 3, 0.80f},     // 20
+    {256, 320, 4, 2, 32, 4, 1, 1.20f},    // 21 staggered, deep ring
+    {256, 256, 4, 2, 32, 4, 1, 1.20f},    // 22 staggered, deep ring
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -75,7 +77,7 @@ static int cg_choose(const AaConvGemm& d, int M) {
     for (int i = 0; i < kNumCgCfgs; ++i) {
         const CgCfg& c = kCgCfgs[i];
         if (d.n_pad % c.bn) continue;
-        if (d.geglu && c.bn != 2 * d.geglu) continue;
+        if (d.geglu && (c.bn / c.wn) % 64) continue;          // value / gate blocks pair up inside one wavefront
         if (forced == i) return i;
         const double tiles = (double)((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
         const double slots = 256.0 * c.per_cu;
@@ -103,7 +105,11 @@ static int cg_splits(const AaConvGemm& d, int M, const CgCfg& c) {
 static bool cg_dma_ok(const AaConvGemm& d) {
     const int n_cols = d.geglu ? d.n_out / 2 : d.n_out;
     return (d.c0 + d.c1) % 64 == 0 && d.c0 % 64 == 0 && d.out_dtype == d.dtype && n_cols % 8 == 0 &&
-           d.ldo % 8 == 0 && aligned16(d.out) && (!d.residual || (d.ldr % 8 == 0 && aligned16(d.residual)));
+           d.ldo % 8 == 0 && aligned16(d.out) && (!d.residual || (d.ldr % 8 == 0 && aligned16(d.residual))) &&
+           d.n_out % 8 == 0 && (!d.bias || d.bias_per_row || aligned16(d.bias)) && (!d.rowvec || aligned16(d.rowvec)) &&
+           // operands are addressed with 32-bit byte offsets through buffer descriptors; offsets >= 2^31 mean "zero"
+           (int64_t)d.n_img * d.h_in * d.w_in * (d.c0 > d.c1 ? d.c0 : d.c1) * 2 < ((int64_t)1 << 31) &&
+           (int64_t)d.n_pad * d.k_pad * 2 < ((int64_t)1 << 31);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER = false>
@@ -137,6 +143,8 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 18: cg_launch_dma<T, 64, 128, 2, 2, 32, 2, 4>(d, m_begin, m_end, splits, stream); break;
         case 19: cg_launch_dma<T, 64, 64, 2, 2, 32, 2, 6>(d, m_begin, m_end, splits, stream); break;
         case 20: cg_launch_dma<T, 64, 256, 2, 2, 32, 2, 3>(d, m_begin, m_end, splits, stream); break;
+        case 21: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1, true>(d, m_begin, m_end, splits, stream); break;
+        case 22: cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1, true>(d, m_begin, m_end, splits, stream); break;
         default: return false;
     }
     return true;
@@ -179,7 +187,7 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
             const int small[2] = {1, 0};
             for (int k = 0; k < 2 && tcfg < 0; ++k) {
                 const CgCfg& t = kCgCfgs[small[k]];
-                if (d.n_pad % t.bn == 0 && (!d.geglu || t.bn == 2 * d.geglu)) tcfg = small[k];
+                if (d.n_pad % t.bn == 0 && (!d.geglu || (t.bn / t.wn) % 64 == 0)) tcfg = small[k];
             }
             if (tcfg < 0) cg_launch_cfg<T>(cfg, d, m_main, M, stream);      // no small tile fits (wide GEGLU): big tile again
             else cg_launch_cfg<T>(tcfg, tail, m_main, M, stream);
@@ -258,6 +266,8 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream) {
         return fail(AA_E_SHAPE, "conv_gemm: bad packed extents n_pad=%d k_pad=%d (K=%d, n_out=%d)", d->n_pad, d->k_pad, d->kh * d->kw * ctot, d->n_out);
     if (d->n_img <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->rowvec_div <= 0)
         return fail(AA_E_SHAPE, "conv_gemm: bad geometry");
+    if (d->geglu && (d->geglu != 32 || d->n_out != d->n_pad || d->bias_per_row))
+        return fail(AA_E_SHAPE, "conv_gemm: GEGLU packs (32 value | 32 gate) column blocks, n_out == n_pad (geglu=%d n_out=%d)", d->geglu, d->n_out);
     if ((int64_t)d->n_img * d->h_out * d->w_out >= (int64_t)1 << 31) return fail(AA_E_SHAPE, "conv_gemm: M overflows int32");
     if (!aligned16(d->a0) || !aligned16(d->a1) || !aligned16(d->w)) return fail(AA_E_ALIGN, "conv_gemm: operands must be 16-byte aligned");
     if (d->out_dtype != AA_F32 && d->out_dtype != d->dtype) return fail(AA_E_DTYPE, "conv_gemm: out_dtype must be dtype or f32");

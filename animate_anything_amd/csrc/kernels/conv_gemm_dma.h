@@ -2,10 +2,10 @@
 //
 // A BM x BN output tile per workgroup, K step BK (64 or 32), WM x WN wavefronts each owning a
 // (BM/WM) x (BN/WN) block of v_mfma_f32_32x32x16 accumulators, a ring of STAGES LDS buffers.
-// Both operand tiles travel HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR round trip, no ds_write):
+// Both operand tiles travel HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write):
 //  * every wave instruction deposits 64 lanes x 16 B, lane-linear = RPI tile rows of BK*2 bytes; the im2col
-//    gather, the conv halo and the M / K tails are expressed in the per-lane SOURCE address (halo lanes read
-//    a 16-byte zero page);
+//    gather, the conv halo and the M / K tails are expressed in the per-lane SOURCE offset of a buffer load
+//    (halo lanes are out of range of the descriptor and deposit zeros);
 //  * bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle applied on the source
 //    side (lane of row r, 16-byte position s fetches k-slot s ^ swz(r)) and undone on the read side;
 //  * requires the K tile to sit inside one filter tap and one concat source ((c0+c1) % 64 == 0 and
@@ -26,9 +26,7 @@
 namespace aa {
 
 __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages) {
-    const int operands = stages * (bm + bn) * bk * 2 + 1024;     // + dummy DMA landing zone
-    const int staging = 128 * (bn + 8) * 2;                      // >= WM*32 rows of the epilogue staging tile
-    return operands > staging ? operands : staging;
+    return stages * (bm + bn) * bk * 2 + 1024 + 1024;             // + dummy DMA landing zone + the tile's bias slice
 }
 
 // PER_CU = workgroups meant to be co-resident on a CU (register budget: 512 / (PER_CU * waves per SIMD)).
@@ -56,10 +54,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * PER_TILE <= 63, "pipeline depth");
     char* smem = dyn_smem();
     char* dummy = smem + STAGES * STAGE_BYTES;           // where surplus (guarded-out) DMA instructions land
+    T* sBias = reinterpret_cast<T*>(dummy + 1024);       // bias of the tile's BN columns (the K-loop barriers publish it)
+    static_assert(BN * 2 <= 1024, "bias slice");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = wave_id();          // scalar (SGPR): everything derived from it stays on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
 
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -74,6 +74,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         if ((p.debug & 8) && tid == 0) reinterpret_cast<long long*>(p.workspace)[(int64_t)blockIdx.x * 8 + slot] = clock_now();
     };
     stamp(0);
+    if (tid < BN / 8) {
+        const int n = tile_n * BN + tid * 8;
+        u32x4 b = u32x4{0u, 0u, 0u, 0u};
+        if (p.bias && !p.bias_per_row && n + 8 <= p.n_out) b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
+        *reinterpret_cast<u32x4*>(sBias + tid * 8) = b;
+    }
     const int ctot = p.c0 + p.c1;
     // split-K: blockIdx.y owns K steps [kbase, kbase + nk) and leaves raw fp32 partial sums in the workspace
     const int nk_all = p.k_pad / BK;
@@ -84,10 +90,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const bool linear = p.kh * p.kw == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 && !resize;
 
     // ---- DMA geometry: this lane feeds LDS rows ((wave + NW*j)*RPI + lane/SPR), 16-byte position lane%SPR ----
+    // Operands are read through buffer descriptors (base in SGPRs, one 32-bit byte offset per lane): halo, tail and
+    // K-padding lanes carry an offset >= 2^31, which the range check of the descriptor turns into 16 zero bytes -
+    // no zero page, no 64-bit per-lane pointers (the host guarantees every operand is < 2 GiB).
+    constexpr unsigned OOB = 0x80000000u;
+    const BufRsrc r_a0 = make_rsrc(p.a0, (unsigned)((int64_t)p.n_img * p.h_in * p.w_in * p.c0 * 2));
+    const BufRsrc r_a1 = make_rsrc(p.a1, p.c1 ? (unsigned)((int64_t)p.n_img * p.h_in * p.w_in * p.c1 * 2) : 0u);
+    const BufRsrc r_w = make_rsrc(p.w, (unsigned)((int64_t)p.n_pad * p.k_pad * 2));
+    const int swm = (p.debug & 16) ? 0 : SPR - 1;        // debug bit 16: no XOR swizzle (probe: LDS bank conflicts of the fragment reads)
     const int lrow = lane / SPR, lpos = lane % SPR;
-    int row_img[AJ], row_iy[AJ], row_ix[AJ], kslot[AJ];
+    int row_img[AJ], iy0[AJ], ix0[AJ];                   // image and top-left tap coordinates of each fed row
+    unsigned ctr0[AJ], ctr1[AJ];                         // byte offset of that pixel (+ this lane's swizzled k-slot) in a0 / a1
     bool row_ok[AJ];
-    int aoff[AJ];                        // element offset of this lane's 16-byte piece inside the source, -1 = zero page
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int rr = (wave + NW * j) * RPI + lrow;
@@ -95,30 +109,30 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         row_ok[j] = m < M && rr < BM;
         const int mm = row_ok[j] ? m : 0;
         if (linear) {                    // 1x1 / nn.Linear: the row IS the pixel, no (img, y, x) decomposition
-            row_img[j] = 0; row_iy[j] = 0; row_ix[j] = mm;
+            row_img[j] = 0; iy0[j] = 0; ix0[j] = mm;
         } else {
             const int x = mm % p.w_out;
             const int t = mm / p.w_out;
             const int y = t % p.h_out;
             row_img[j] = t / p.h_out;
-            row_iy[j] = y * p.stride - p.pad_h;
-            row_ix[j] = x * p.stride - p.pad_w;
+            iy0[j] = y * p.stride - p.pad_h;
+            ix0[j] = x * p.stride - p.pad_w;
         }
-        kslot[j] = lpos ^ ((rr / RPB) % SPR);
-        aoff[j] = -1;
+        const int slot8 = (lpos ^ ((rr / RPB) & swm)) * 8;
+        const int pix = (row_img[j] * p.h_in + iy0[j]) * p.w_in + ix0[j];      // may be "negative": only used for in-range taps
+        ctr0[j] = (unsigned)(pix * p.c0 + slot8) * 2u;
+        ctr1[j] = (unsigned)(pix * p.c1 + slot8) * 2u;
     }
-    // weight panel of this tile: 32-bit element offsets (a packed panel is far below 2^31 elements)
-    const T* wtile = reinterpret_cast<const T*>(p.w) + (int64_t)tile_n * BN * p.k_pad;
-    int woff[BJ];
+    // weight panel of this tile: byte offsets into the packed tensor
+    unsigned wb[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
         const int rr = (wave + NW * j) * RPI + lrow;
-        woff[j] = rr * p.k_pad + (lpos ^ ((rr / RPB) % SPR)) * 8;
+        wb[j] = (unsigned)((tile_n * BN + rr) * p.k_pad + (lpos ^ ((rr / RPB) & swm)) * 8) * 2u;
     }
-    const T* zero = reinterpret_cast<const T*>(zero_page());
 
     int cur_tap = -1;
-    int pixel[AJ];                       // source pixel of each fed row for the current tap (-1 = halo / tail)
+    unsigned pb0[AJ], pb1[AJ];           // byte offset of each fed row's source pixel for the current tap (OOB = halo / tail)
     auto issue = [&](int kt, int buf) {
         // K order (wave-uniform scalars): tap-major (tap, channel) or, for multi-tap filters packed
         // chunk-major, (64-channel chunk, tap, channel) - consecutive K steps then re-read the same
@@ -132,35 +146,42 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             cur_tap = tap;
             const int dy = tap / p.kw, dx = tap - dy * p.kw;
             const bool tap_ok = tap < p.kh * p.kw;
+            const int d = dy * p.w_in + dx;
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
-                const int iy = row_iy[j] + dy, ix = row_ix[j] + dx;
-                if (linear) { pixel[j] = (tap_ok && row_ok[j]) ? ix : -1; continue; }
+                const int iy = iy0[j] + dy, ix = ix0[j] + dx;
                 const bool ok = tap_ok && row_ok[j] && (unsigned)iy < (unsigned)p.h_virt && (unsigned)ix < (unsigned)p.w_virt;
-                int sy = iy, sx = ix;
-                if (resize) { sy = (iy * p.h_in) / p.h_virt; sx = (ix * p.w_in) / p.w_virt; }
-                pixel[j] = ok ? (row_img[j] * p.h_in + sy) * p.w_in + sx : -1;
+                if (!resize) {
+                    pb0[j] = ok ? ctr0[j] + (unsigned)(d * p.c0) * 2u : OOB;
+                    pb1[j] = ok ? ctr1[j] + (unsigned)(d * p.c1) * 2u : OOB;
+                } else {                                                       // nearest-neighbour resize in front (Upsample2D)
+                    const int sy = (iy * p.h_in) / p.h_virt, sx = (ix * p.w_in) / p.w_virt;
+                    const int pix = (row_img[j] * p.h_in + sy) * p.w_in + sx;
+                    const int rr = (wave + NW * j) * RPI + lrow;
+                    const int slot8 = (lpos ^ ((rr / RPB) & swm)) * 8;
+                    pb0[j] = ok ? (unsigned)(pix * p.c0 + slot8) * 2u : OOB;
+                    pb1[j] = ok ? (unsigned)(pix * p.c1 + slot8) * 2u : OOB;
+                }
             }
         }
-        const T* src; int cs, cc;
-        if (cb < p.c0) { src = reinterpret_cast<const T*>(p.a0); cs = p.c0; cc = cb; }
-        else           { src = reinterpret_cast<const T*>(p.a1); cs = p.c1; cc = cb - p.c0; }
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) aoff[j] = pixel[j] >= 0 ? pixel[j] * cs + cc + kslot[j] * 8 : -1;
+        const bool src1 = cb >= p.c0;
+        const unsigned ccb = (unsigned)(src1 ? cb - p.c0 : cb) * 2u;
+        const BufRsrc ra = src1 ? r_a1 : r_a0;
         char* a = smem + buf * STAGE_BYTES + wave * RPI * ROWB;
         char* b = smem + buf * STAGE_BYTES + BM * ROWB + wave * RPI * ROWB;
-        // every wave issues exactly PER_TILE instructions (vmcnt bookkeeping): groups past the tile edge are
-        // pointed at the zero page / the dummy landing zone (wave-uniform choice)
+        const bool dry = p.debug & 32;                   // debug bit 32: every piece is out of range (issue cost without memory traffic)
+        // every wave issues exactly PER_TILE instructions (vmcnt bookkeeping): groups past the tile edge read
+        // out of range and land in the dummy zone (wave-uniform choice)
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const bool real = (GA % NW == 0) || (wave + NW * j < GA);
-            const T* g = (real && aoff[j] >= 0) ? src + aoff[j] : zero;
-            async_copy16(g, real ? a + j * NW * RPI * ROWB : dummy);
+            async_copy16_buf(ra, (real && !dry) ? (src1 ? pb1[j] : pb0[j]) + ccb : OOB, real ? a + j * NW * RPI * ROWB : dummy);
         }
+        const unsigned kb = (unsigned)((kbase + kt) * BK) * 2u;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const bool real = (GB % NW == 0) || (wave + NW * j < GB);
-            async_copy16(real ? wtile + woff[j] + (kbase + kt) * BK : zero, real ? b + j * NW * RPI * ROWB : dummy);
+            async_copy16_buf(r_w, (real && !dry) ? wb[j] + kb : OOB, real ? b + j * NW * RPI * ROWB : dummy);
         }
     };
 
@@ -176,9 +197,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const int frow = lane & 31, fh = lane >> 5;
     int a_off[MI], b_off[NI], a_swz[MI], b_swz[NI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) { const int rr = wm * (BM / WM) + i * 32 + frow; a_off[i] = rr * ROWB; a_swz[i] = (rr / RPB) % SPR; }
+    for (int i = 0; i < MI; ++i) { const int rr = wm * (BM / WM) + i * 32 + frow; a_off[i] = rr * ROWB; a_swz[i] = (rr / RPB) & swm; }
+    // weights are the MFMA "A" operand (rows -> accumulator registers); MFMA row r is fed tile row pi(r) =
+    // (r&3) + 4*(r>>3) + 16*((r>>2)&1), which makes the 16 registers of a lane 16 consecutive output columns
+    const int prow = (frow & 3) + 4 * (frow >> 3) + 16 * ((frow >> 2) & 1);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + frow; b_off[j] = BM * ROWB + rr * ROWB; b_swz[j] = (rr / RPB) % SPR; }
+    for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + prow; b_off[j] = BM * ROWB + rr * ROWB; b_swz[j] = (rr / RPB) & swm; }
 
     // Fragment reads.  FRAG_ASM: two register sets, the ds_reads of sub-step ks+1 are hand-issued before the
     // MFMAs of sub-step ks and waited with a counted lgkmcnt (LDS returns in order: "at most MI+NI outstanding"
@@ -210,7 +234,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fa[set][i], fb[set][j], acc[i][j]);
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fb[set][j], fa[set][i], acc[i][j]);
             }
         } else {
 #pragma unroll
@@ -223,33 +247,22 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fa[i], fb[j], acc[i][j]);
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fb[j], fa[i], acc[i][j]);
             }
         }
     };
 
+    // -DAA_PHASE_PROBE build (scripts/phase_probe.py): wave 0 sums the cycles it spends waiting for DMA, at the
+    // barrier, issuing DMA and in the multiply over the K loop -> workspace[65536 + bid][0..3]
+#ifdef AA_PHASE_PROBE
+    long long pt[4] = {0, 0, 0, 0};
+    long long plast = clock_now();
+#define AA_TICK(k) { const long long now_ = clock_now(); pt[k] += now_ - plast; plast = now_; }
+#else
+#define AA_TICK(k)
+#endif
     stamp(1);
-    if constexpr (STAGGER) {
-        // Two wave groups (first / second wave of every SIMD) run half a K step apart: while one group
-        // multiplies tile kt the other only issues / waits for DMA, so the matrix pipe never sees both waves
-        // parked at the same barrier.  Two barriers per K step, two LDS buffers:
-        //   interval 2k  : both issue their share of tile kt+1 -> buffer (kt+1)&1 (its last reader, the late
-        //                  group's multiply of tile kt-1, finished before the previous barrier); EARLY multiplies kt
-        //   interval 2k+1: LATE multiplies tile kt; both drain their own DMA share before the closing barrier.
-        static_assert(!STAGGER || (STAGES == 2 && NW == 8), "stagger needs 8 waves and a 2-buffer ring");
-        const bool late = wave >= NW / 2;
-        issue(0, 0);
-        dma_wait<0>();
-        block_barrier();
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-            if (!late) compute(kt & 1);
-            block_barrier();
-            if (late) compute(kt & 1);
-            dma_wait<0>();
-            block_barrier();
-        }
-    } else {
+    {
 #pragma unroll
         for (int t = 0; t < DIST; ++t)
             if (t < nk) issue(t, t);
@@ -259,112 +272,136 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             if (DIST >= 3 && younger == 2) dma_wait<2 * PER_TILE>();
             else if (DIST >= 2 && younger >= 1) dma_wait<(DIST >= 2 ? PER_TILE : 0)>();
             else dma_wait<0>();
+            AA_TICK(0)
             block_barrier();                 // everyone's share of tile kt landed; buffer (kt-1)%STAGES is free
+            AA_TICK(1)
+            // STAGGER: the second wave of every SIMD (waves NW/2..) multiplies first and issues afterwards, its partner the
+            // other way round: a SIMD then always has one wave feeding the matrix pipe while the other sits in the (CU-wide,
+            // ~20 clk per instruction) LDS-DMA issue queue - instead of eight waves queueing there together.
+            const bool mult_first = STAGGER && wave >= NW / 2;
+            if (mult_first && !(p.debug & 2)) compute(kt % STAGES);
             if (kt + DIST < nk && !(p.debug & 1)) issue(kt + DIST, (kt + DIST) % STAGES);
-            if (!(p.debug & 2)) compute(kt % STAGES);
+            AA_TICK(2)
+            if (!mult_first && !(p.debug & 2)) compute(kt % STAGES);
+            AA_TICK(3)
         }
     }
+#ifdef AA_PHASE_PROBE
+    if ((p.debug & 8) && tid == 0)
+        for (int k = 0; k < 4; ++k) reinterpret_cast<long long*>(p.workspace)[((int64_t)65536 + blockIdx.x) * 8 + k] = pt[k];
+#endif
+#undef AA_TICK
 
     stamp(2);
+    const int ec = lane & 31, eh = lane >> 5;              // epilogue: lane owns output row ec, columns 16*eh .. +15 of a block
+    const int m_tile = m_begin + tile_m * BM;
+    const int n_wave = tile_n * BN + wn * (BN / WN);
     if (k_splits > 1) {
-        // partial sums straight from the accumulator layout (col = lane&31, 4-row groups): ws[split][m][n] fp32
+        // partial sums straight from the accumulator layout: ws[split][m][n] fp32, 64 contiguous bytes per lane and block
         float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)blockIdx.y * M * p.n_pad;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
+            const int m = m_tile + wm * (BM / WM) + i * 32 + ec;
+            if (m >= M) continue;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const int n = tile_n * BN + wn * (BN / WN) + j * 32 + (lane & 31);
+                float* dst = ws + (int64_t)m * p.n_pad + n_wave + j * 32 + 16 * eh;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m_begin + tile_m * BM + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (m < M) ws[(int64_t)m * p.n_pad + n] = acc[i][j][e];
-                }
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
             }
+        }
         return;
     }
 
-    // ---- epilogue: pass i stages accumulator block-row i of EVERY wave (WM*32 tile rows) through an LDS
-    // tile [WM*32][BN+8] of storage dtype; acc[i] is dead after pass i, so register pressure only falls ----
-    constexpr int LDE = BN + 8;
-    constexpr int PROWS = WM * 32;                       // tile rows staged per pass
-    T* sE = reinterpret_cast<T*>(smem);
-    const T* bias = reinterpret_cast<const T*>(p.bias);
+    // ---- epilogue, straight from the accumulators (no LDS tile, no barrier): the weight fragments were the MFMA
+    // "A" operand with their rows permuted by pi, so lane (ec, eh) holds out[m = ec][16*eh + e] in acc[i][j][e] -
+    // 16 consecutive columns = two 16-byte stores per block; bias (from LDS), time-embedding row vector, SiLU,
+    // GEGLU (value block j, gate block j+1 sit in the same lane) and the residual are applied on the way out.
     const T* rowvec = reinterpret_cast<const T*>(p.rowvec);
     const T* resid = reinterpret_cast<const T*>(p.residual);
+    const T* bias = reinterpret_cast<const T*>(p.bias);
     T* out = reinterpret_cast<T*>(p.out);
-    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-    const int m_tile = m_begin + tile_m * BM;
-    const int g0 = m_tile / p.rowvec_div;
-    const int g_edge = (g0 + 1) * p.rowvec_div;
-    // rows of one tile fall into at most two row-vector groups when rowvec_div >= BM (always true on the
-    // UNet path: rowvec_div = frames*H*W); otherwise divide per element.
-    const bool two_groups = p.rowvec_div >= BM;
     const int n_cols = p.geglu ? (p.n_out >> 1) : p.n_out;
-
-    // per-column terms are the same in every pass: hoist them
-    float bcol[NI], rv0[NI], rv1[NI];
-    int nbj[NI];
+    const bool post = resid || p.out_scale != 1.0f;
+    const bool pre_is_rv = rowvec != nullptr;             // the prefetch registers carry the row vector, else the residual
+#define AA_ZERO4 (u32x4{0u, 0u, 0u, 0u})          /* a prvalue: `c ? arr[i] : zero_variable` would select between ADDRESSES and pin arr in scratch */
+    auto col_of = [&](int j) __attribute__((always_inline)) { return p.geglu ? (n_wave >> 1) + (j >> 1) * 32 + 16 * eh : n_wave + j * 32 + 16 * eh; };
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = min(tile_n * BN + wn * (BN / WN) + j * 32 + col_l, p.n_pad - 1);
-        nbj[j] = p.geglu ? n : min(n, p.n_out - 1);       // GEGLU bias is packed like the weights
-        bcol[j] = (bias && !p.bias_per_row) ? (float)bias[nbj[j]] : 0.0f;
-        rv0[j] = 0.0f; rv1[j] = 0.0f;
-        if (rowvec && two_groups) {
-            const int gmax = (M - 1) / p.rowvec_div;
-            rv0[j] = (float)rowvec[(int64_t)min(g0, gmax) * p.n_out + nbj[j]];
-            rv1[j] = (float)rowvec[(int64_t)min(g0 + 1, gmax) * p.n_out + nbj[j]];
-        }
-    }
-
-    // row-major read-back of one staged pass, CPR = 16-byte chunks per output row (compile-time: no divides)
-    auto read_back = [&](int ps, auto cpr_tag) {
-        constexpr int CPR = decltype(cpr_tag)::value;
-        const int col0 = tile_n * CPR * 8;
-        for (int c = tid; c < PROWS * CPR; c += THREADS) {
-            const int rl = c / CPR, ch = c - rl * CPR;
-            const int m = m_tile + (rl >> 5) * (BM / WM) + ps * 32 + (rl & 31), n = col0 + ch * 8;
-            if (m >= M || n >= n_cols) continue;
-            Pack8<T> v; v.raw = *reinterpret_cast<const u32x4*>(sE + rl * LDE + ch * 8);
-            if (CPR * 8 != BN) {                          // GEGLU: value half | gate half of the tile
-                Pack8<T> gt; gt.raw = *reinterpret_cast<const u32x4*>(sE + rl * LDE + CPR * 8 + ch * 8);
+    for (int i = 0; i < MI; ++i) {
+        const int m = m_tile + wm * (BM / WM) + i * 32 + ec;
+        const bool m_ok = m < M;
+        const int mc = m_ok ? m : M - 1;
+        const float brow = (p.bias_per_row && bias) ? (float)bias[mc] : 0.0f;
+        const T* rv = rowvec ? rowvec + (int64_t)(mc / p.rowvec_div) * p.n_out : nullptr;
+        const T* rs = resid ? resid + (int64_t)mc * p.ldr : nullptr;
+        // one block-row of row-vector (or residual) pieces is fetched up front so their latency overlaps
+        u32x4 pre[NI][2];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v.e[e] = (T)((float)v.e[e] * gelu_erf_f((float)gt.e[e]));
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int n_rv = n_wave + j * 32 + 16 * eh + 8 * q, n_rs = col_of(j) + 8 * q;
+                const bool ok = pre_is_rv ? (n_rv + 8 <= p.n_out) : (rs != nullptr && !(p.geglu && (j & 1)) && n_rs + 8 <= n_cols);
+                const T* src = pre_is_rv ? rv + n_rv : rs + n_rs;
+                pre[j][q] = ok ? *reinterpret_cast<const u32x4*>(src) : AA_ZERO4;
             }
-            if (resid || p.out_scale != 1.0f) {
-                Pack8<T> rs; rs.raw = u32x4{0u, 0u, 0u, 0u};
-                if (resid) rs.raw = *reinterpret_cast<const u32x4*>(resid + (int64_t)m * p.ldr + n);
+        auto finish_block = [&](int j, Pack8<T> (&o)[2]) __attribute__((always_inline)) {   // residual / scale and the two stores of one 32x32 block
+            const int nc = col_of(j);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v.e[e] = (T)(((float)v.e[e] + (float)rs.e[e]) * p.out_scale);
+            for (int q = 0; q < 2; ++q) {
+                const u32x4 pv = pre[j][q];               // (read unconditionally: a load in only one branch gets merged with the
+                if (post) {                               //  global load of the other into one load through a selected POINTER)
+                    Pack8<T> r; r.raw = AA_ZERO4;
+                    if (rs) { if (pre_is_rv) { if (nc + 8 * q + 8 <= n_cols) r.raw = *reinterpret_cast<const u32x4*>(rs + nc + 8 * q); } else r.raw = pv; }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[q].e[e] = (T)(((float)o[q].e[e] + (float)r.e[e]) * p.out_scale);
+                }
+                if (m_ok && nc + 8 * q + 8 <= n_cols) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o[q].raw;
             }
-            *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + n) = v.raw;
-        }
-    };
-
+        };
+        auto block_vals = [&](int j, Pack8<T> (&o)[2]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU), rounded to storage type
 #pragma unroll
-    for (int ps = 0; ps < MI; ++ps) {
-        __syncthreads();                                  // previous users of the LDS region are done
+            for (int q = 0; q < 2; ++q) {
+                Pack8<T> b; b.raw = *reinterpret_cast<const u32x4*>(sBias + (wn * (BN / WN) + j * 32 + 16 * eh + 8 * q));
+                const u32x4 pv = pre[j][q];
+                Pack8<T> r; r.raw = AA_ZERO4;
+                if (pre_is_rv) r.raw = pv;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int nl = wn * (BN / WN) + j * 32 + col_l;
+                for (int e = 0; e < 8; ++e) {
+                    float v = acc[i][j][8 * q + e] + (float)b.e[e] + brow;
+                    if (pre_is_rv) v += (float)r.e[e];
+                    if (p.act == AA_ACT_SILU) v = silu_f(v);
+                    o[q].e[e] = (T)v;
+                }
+            }
+        };
+        if (p.geglu) {
+            if constexpr (NI % 2 == 0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rl = wm * 32 + (e & 3) + 8 * (e >> 2) + row_l;               // staged row
-                const int m = min(m_tile + wm * (BM / WM) + ps * 32 + (e & 3) + 8 * (e >> 2) + row_l, M - 1);
-                float v = acc[ps][j][e] + bcol[j];
-                if (p.bias_per_row && bias) v += (float)bias[m];
-                if (rowvec) v += two_groups ? (m < g_edge ? rv0[j] : rv1[j]) : (float)rowvec[(int64_t)(m / p.rowvec_div) * p.n_out + nbj[j]];
-                if (p.act == AA_ACT_SILU) v = silu_f(v);
-                sE[rl * LDE + nl] = (T)v;
+                for (int j = 0; j < NI; j += 2) {
+                    Pack8<T> val[2], gate[2];
+                    block_vals(j, val);
+                    block_vals(j + 1, gate);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) val[q].e[e] = (T)((float)val[q].e[e] * gelu_erf_f((float)gate[q].e[e]));
+                    finish_block(j, val);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                Pack8<T> o[2];
+                block_vals(j, o);
+                finish_block(j, o);
             }
         }
-        __syncthreads();
-        if (ps == 0) stamp(3);
-        if (p.geglu) read_back(ps, IntTag<BN / 16>());
-        else read_back(ps, IntTag<BN / 8>());
-        if (ps == 0) stamp(4);
+        if (i == 0) stamp(3);
     }
     stamp(5);
+#undef AA_ZERO4
 }
 
 }  // namespace aa

@@ -54,6 +54,18 @@ __device__ __forceinline__ void async_copy16(const void* gsrc, void* lds_wave_ba
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same through a buffer descriptor: wave-uniform base + range (SGPRs) and one 32-bit byte offset per lane; a lane
+// whose offset is out of range deposits 16 zero bytes (buffer_load_dwordx4 ... offen lds).
+struct BufRsrc { __amdgpu_buffer_rsrc_t v; };
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) {
+    return BufRsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.v, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_offset, 0, 0, 0);
+}
+// Index of this wavefront inside the workgroup, as a scalar.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // Counted wait on this wave's outstanding vector-memory operations (LDS-DMA included): returns once at
 // most N are still in flight, i.e. everything issued before the N youngest has landed.
 template <int N>

@@ -29,11 +29,10 @@ TRACE = None
 AUTOTUNE = True
 LAST_STAMPS = None
 DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
-GEGLU_GRAN = 0        # 0: automatic (160 when the inner width allows, else 64); 64 / 160 force a packing
 # (BM, BN, BK, stages) - mirrors the table in csrc/aa_api_impl.h
 TILE_TABLE = ((128, 64, 64, 2), (128, 128, 64, 2), (192, 256, 64, 2), (256, 256, 64, 2), (256, 320, 64, 2), (192, 320, 64, 2),
               (256, 320, 32, 4), (256, 256, 32, 4), (128, 128, 32, 4), (128, 64, 32, 4), (192, 320, 32, 4),
-              (128, 320, 32, 2), (128, 256, 32, 2), (128, 256, 64, 2), (256, 320, 64, 2), (256, 256, 64, 2), (128, 128, 32, 2), (128, 64, 32, 2), (64, 128, 32, 2), (64, 64, 32, 2), (64, 256, 32, 2))
+              (128, 320, 32, 2), (128, 256, 32, 2), (128, 256, 64, 2), (256, 320, 64, 2), (256, 256, 64, 2), (128, 128, 32, 2), (128, 64, 32, 2), (64, 128, 32, 2), (64, 64, 32, 2), (64, 256, 32, 2), (256, 320, 32, 4), (256, 256, 32, 4))
 _tile_cache = {}
 
 
@@ -59,7 +58,7 @@ def _tile_candidates(d):
     for i, (bm, bn, _bk, _st) in enumerate(TILE_TABLE):
         if d.n_pad % bn:
             continue
-        if d.geglu and bn != 2 * d.geglu:
+        if d.geglu and (bn // 2) % 64:                     # (every table entry has 2 wave columns)
             continue
         out.append(i)
     return out
@@ -144,7 +143,8 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     """Pack an nn.Linear [n,k], nn.Conv2d [n,c,kh,kw] or nn.Conv3d [n,c,kt,1,1] weight.
 
     GEGLU (diffusers `GEGLU.proj`, rows [0,d) = value, [d,2d) = gate) is re-ordered into alternating
-    blocks of G value rows / G gate rows (G = 160 or 64) so that both halves of a pair land in one tile."""
+    blocks of 32 value rows / 32 gate rows: a value block and its gate block are then neighbouring accumulator
+    blocks of the same wavefront and the gating happens in registers."""
     w = weight.detach()
     if w.dim() == 2:
         n, kh, kw, cin = w.shape[0], 1, 1, w.shape[1]
@@ -171,8 +171,8 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     b = None if bias is None else bias.detach()
     if geglu:
         d = n // 2
-        gran = GEGLU_GRAN or (160 if d % 160 == 0 else 64)   # half the width of the tile shape that will own the pair
-        assert d % gran == 0, "GEGLU inner width must be a multiple of 64"
+        gran = 32                                          # one 32-column accumulator block of value, the next one of gate
+        assert d % gran == 0, "GEGLU inner width must be a multiple of 32"
         val = torch.arange(d, device=w.device).reshape(d // gran, 1, gran)
         src = torch.cat([val, val + d], dim=1).reshape(-1)
         w2 = w2[src]
@@ -272,7 +272,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     need = lib.aa_conv_gemm_workspace(C.byref(d))        # split-K scratch for few-tile / long-K calls
     if DEBUG_ABLATE & 8:                                  # phase probe: [workgroup][8] shader-clock stamps
         global LAST_STAMPS
-        ws = LAST_STAMPS = torch.zeros(1 << 16, 8, dtype=torch.int64, device=x0.device)
+        ws = LAST_STAMPS = torch.zeros(2, 1 << 16, 8, dtype=torch.int64, device=x0.device)
         d.workspace, d.workspace_bytes = _ptr(ws), ws.numel() * 8
     elif need:
         ws = torch.empty(need // 4, dtype=torch.float32, device=x0.device)

@@ -59,8 +59,8 @@ const char* aa_last_error(void);
  * + residual[m, n]; * out_scale; store as `out_dtype`.
  * W is pre-packed by the host: [n_pad, k_pad] row-major, k ordered (tap, channel) - or, see k_order,
  * (64-channel chunk, tap, channel) for multi-tap filters - zero padded,
- * and for GEGLU interleaved in blocks of `geglu` value rows / `geglu` gate rows (geglu = 64 or 160:
- * half the width of the tile that will own the pair).
+ * and for GEGLU interleaved in blocks of 32 value rows / 32 gate rows (geglu = 32: the value block and its gate
+ * block are neighbouring 32-column accumulator blocks of one wavefront; needs n_out == n_pad).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct AaConvGemm {
     const void* a0;
@@ -78,7 +78,7 @@ typedef struct AaConvGemm {
     int32_t rowvec_div;
     int32_t ldo, ldr;
     int32_t act;           /* AA_ACT_* */
-    int32_t geglu;         /* 0, or G: packed columns are (G value | G gate) blocks, output has n_out/2 columns */
+    int32_t geglu;         /* 0, or 32: packed columns are (32 value | 32 gate) blocks, output has n_out/2 columns */
     int32_t bias_per_row;
     int32_t dtype;         /* AA_F16 | AA_BF16: activations + weights */
     int32_t out_dtype;     /* AA_F16 | AA_BF16 (== dtype) or AA_F32 */

@@ -200,6 +200,15 @@ inline void async_copy16(const void* gsrc, void* lds_wave_base) {
     std::memcpy(static_cast<char*>(lds_wave_base) + (emu::linear_tid() & 63) * 16, gsrc, 16);
 }
 
+struct BufRsrc { const char* base; unsigned bytes; };
+inline BufRsrc make_rsrc(const void* base, unsigned bytes) { return BufRsrc{static_cast<const char*>(base), bytes}; }
+inline void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_wave_base) {
+    char* dst = static_cast<char*>(lds_wave_base) + (emu::linear_tid() & 63) * 16;
+    if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(dst, r.base + byte_offset, 16);
+    else std::memset(dst, 0, 16);
+}
+inline int wave_id() { return emu::linear_tid() >> 6; }
+
 template <int N>
 inline void dma_wait() {}                       // the emulator's DMA is synchronous
 inline void block_barrier() { emu::block_barrier(); }
