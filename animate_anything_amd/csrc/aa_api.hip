@@ -7,13 +7,13 @@ namespace aa {
 // must opt in once per function.
 template <typename K>
 static void ensure_lds(K kernel, size_t lds_bytes) {
-    static thread_local const void* done[16];
+    static thread_local const void* done[256];
     static thread_local int n_done = 0;
     if (lds_bytes <= 64 * 1024) return;
     const void* key = reinterpret_cast<const void*>(kernel);
     for (int i = 0; i < n_done; ++i) if (done[i] == key) return;
     (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (n_done < 16) done[n_done++] = key;
+    if (n_done < 256) done[n_done++] = key;
 }
 }  // namespace aa
 

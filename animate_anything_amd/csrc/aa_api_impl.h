@@ -104,7 +104,7 @@ static int cg_splits(const AaConvGemm& d, int M, const CgCfg& c) {
 
 static bool cg_dma_ok(const AaConvGemm& d) {
     const int n_cols = d.geglu ? d.n_out / 2 : d.n_out;
-    return (d.c0 + d.c1) % 64 == 0 && d.c0 % 64 == 0 && d.out_dtype == d.dtype && n_cols % 8 == 0 &&
+    return (d.c0 + d.c1) % 64 == 0 && d.c0 % 64 == 0 && d.kh <= 8 && d.kw <= 8 && d.out_dtype == d.dtype && n_cols % 8 == 0 &&
            d.ldo % 8 == 0 && aligned16(d.out) && (!d.residual || (d.ldr % 8 == 0 && aligned16(d.residual))) &&
            d.n_out % 8 == 0 && (!d.bias || d.bias_per_row || aligned16(d.bias)) && (!d.rowvec || aligned16(d.rowvec)) &&
            // operands are addressed with 32-bit byte offsets through buffer descriptors; offsets >= 2^31 mean "zero"

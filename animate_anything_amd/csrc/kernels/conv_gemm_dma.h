@@ -99,29 +99,36 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const BufRsrc r_w = make_rsrc(p.w, (unsigned)((int64_t)p.n_pad * p.k_pad * 2));
     const int swm = (p.debug & 16) ? 0 : SPR - 1;        // debug bit 16: no XOR swizzle (probe: LDS bank conflicts of the fragment reads)
     const int lrow = lane / SPR, lpos = lane % SPR;
-    int row_img[AJ], iy0[AJ], ix0[AJ];                   // image and top-left tap coordinates of each fed row
-    unsigned ctr0[AJ], ctr1[AJ];                         // byte offset of that pixel (+ this lane's swizzled k-slot) in a0 / a1
-    bool row_ok[AJ];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
+    // per fed activation row: byte offset of its top-left tap pixel (+ this lane's swizzled k-slot) in a0 / a1, and which
+    // taps read a real pixel: bits 0..7 = rows dy inside the image, bits 8..15 = columns dx (0 for rows outside the tile)
+    unsigned ctr0[AJ], ctr1[AJ], vmask[AJ];
+    struct RowCoords { int img, iy, ix; bool ok; };
+    auto row_coords = [&](int j) __attribute__((always_inline)) {
         const int rr = (wave + NW * j) * RPI + lrow;
         const int m = m_begin + tile_m * BM + rr;
-        row_ok[j] = m < M && rr < BM;
-        const int mm = row_ok[j] ? m : 0;
-        if (linear) {                    // 1x1 / nn.Linear: the row IS the pixel, no (img, y, x) decomposition
-            row_img[j] = 0; iy0[j] = 0; ix0[j] = mm;
-        } else {
-            const int x = mm % p.w_out;
-            const int t = mm / p.w_out;
-            const int y = t % p.h_out;
-            row_img[j] = t / p.h_out;
-            iy0[j] = y * p.stride - p.pad_h;
-            ix0[j] = x * p.stride - p.pad_w;
-        }
+        const bool ok = m < M && rr < BM;
+        const int mm = ok ? m : 0;
+        if (linear) return RowCoords{0, 0, mm, ok};                               // 1x1 / nn.Linear: the row IS the pixel
+        const int x = mm % p.w_out;
+        const int t = mm / p.w_out;
+        const int y = t % p.h_out;
+        return RowCoords{t / p.h_out, y * p.stride - p.pad_h, x * p.stride - p.pad_w, ok};
+    };
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const RowCoords rc = row_coords(j);
+        const int img = rc.img, iy = rc.iy, ix = rc.ix;
+        const bool ok = rc.ok;
+        const int rr = (wave + NW * j) * RPI + lrow;
         const int slot8 = (lpos ^ ((rr / RPB) & swm)) * 8;
-        const int pix = (row_img[j] * p.h_in + iy0[j]) * p.w_in + ix0[j];      // may be "negative": only used for in-range taps
+        const int pix = (img * p.h_in + iy) * p.w_in + ix;                        // may be "negative": only used for in-range taps
         ctr0[j] = (unsigned)(pix * p.c0 + slot8) * 2u;
         ctr1[j] = (unsigned)(pix * p.c1 + slot8) * 2u;
+        // taps dy with 0 <= iy + dy < h_virt form an interval [lo, hi) (same for dx): two shifts instead of a loop
+        const int ylo = max(0, -iy), yhi = max(ylo, min(p.kh, p.h_virt - iy));
+        const int xlo = max(0, -ix), xhi = max(xlo, min(p.kw, p.w_virt - ix));
+        const unsigned my = ((1u << yhi) - 1u) ^ ((1u << ylo) - 1u), mx = ((1u << xhi) - 1u) ^ ((1u << xlo) - 1u);
+        vmask[j] = ok ? (my | (mx << 8)) : 0u;
     }
     // weight panel of this tile: byte offsets into the packed tensor
     unsigned wb[BJ];
@@ -131,32 +138,59 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         wb[j] = (unsigned)((tile_n * BN + rr) * p.k_pad + (lpos ^ ((rr / RPB) & swm)) * 8) * 2u;
     }
 
+    const int taps = p.kh * p.kw;
+
+    // K position of the NEXT issue() call as wave-uniform scalars, advanced incrementally (issue() is called for
+    // consecutive K tiles): tap-major order (tap, channel) or, for multi-tap filters packed chunk-major,
+    // (64-channel chunk, tap, channel) - consecutive K steps then re-read the same activation slab shifted by one tap,
+    // which keeps it L2-resident across the 9 taps.
+    int n_tap, n_dy, n_dx, n_cb;
+    {
+        const int k0 = kbase * BK;
+        if (p.k_order) { const int unit = k0 >> 6; const int chunk = unit / taps; n_tap = unit - chunk * taps; n_cb = chunk * 64 + (k0 & 63); }
+        else           { n_tap = k0 / ctot; n_cb = k0 - n_tap * ctot; }
+        n_dy = n_tap / p.kw; n_dx = n_tap - n_dy * p.kw;
+    }
     int cur_tap = -1;
     unsigned pb0[AJ], pb1[AJ];           // byte offset of each fed row's source pixel for the current tap (OOB = halo / tail)
     auto issue = [&](int kt, int buf) {
-        // K order (wave-uniform scalars): tap-major (tap, channel) or, for multi-tap filters packed
-        // chunk-major, (64-channel chunk, tap, channel) - consecutive K steps then re-read the same
-        // activation slab shifted by one tap, which keeps it L2-resident across the 9 taps.
-        const int k0 = (kbase + kt) * BK;
-        int tap, cb;
-        if (p.k_order) { const int taps = p.kh * p.kw; const int unit = k0 >> 6; const int chunk = unit / taps;
-                         tap = unit - chunk * taps; cb = chunk * 64 + (k0 & 63); }
-        else           { tap = k0 / ctot; cb = k0 - tap * ctot; }
+        const int tap = n_tap, cb = n_cb, dy = n_dy, dx = n_dx;
+        // advance to the next K tile (selects, not `++x` in branches: those get tail-merged into one increment through
+        // a selected POINTER, which pins the counters in scratch)
+        {
+            const bool wrap_x = n_dx + 1 == p.kw;
+            if (p.k_order) {
+                const bool half = BK == 32 && !(n_cb & 32);              // first half of a 64-channel unit: same tap
+                const bool last_tap = n_tap + 1 == taps;
+                const int cb_unit = (n_cb & ~63) + (last_tap ? 64 : 0);
+                const int t1 = last_tap ? 0 : n_tap + 1;
+                const int y1 = last_tap ? 0 : (wrap_x ? n_dy + 1 : n_dy);
+                const int x1 = (last_tap || wrap_x) ? 0 : n_dx + 1;
+                n_cb = half ? n_cb + 32 : cb_unit;
+                n_tap = half ? n_tap : t1; n_dy = half ? n_dy : y1; n_dx = half ? n_dx : x1;
+            } else {
+                const bool last_c = n_cb + BK >= ctot;
+                n_cb = last_c ? 0 : n_cb + BK;
+                n_tap = last_c ? n_tap + 1 : n_tap;
+                n_dy = (last_c && wrap_x) ? n_dy + 1 : n_dy;
+                n_dx = last_c ? (wrap_x ? 0 : n_dx + 1) : n_dx;
+            }
+        }
         if (tap != cur_tap) {
             cur_tap = tap;
-            const int dy = tap / p.kw, dx = tap - dy * p.kw;
-            const bool tap_ok = tap < p.kh * p.kw;
             const int d = dy * p.w_in + dx;
+            const unsigned d0 = (unsigned)(d * p.c0) * 2u, d1 = (unsigned)(d * p.c1) * 2u;
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
-                const int iy = iy0[j] + dy, ix = ix0[j] + dx;
-                const bool ok = tap_ok && row_ok[j] && (unsigned)iy < (unsigned)p.h_virt && (unsigned)ix < (unsigned)p.w_virt;
+                const bool ok = tap < taps && (((vmask[j] >> dy) & (vmask[j] >> (8 + dx))) & 1u);
                 if (!resize) {
-                    pb0[j] = ok ? ctr0[j] + (unsigned)(d * p.c0) * 2u : OOB;
-                    pb1[j] = ok ? ctr1[j] + (unsigned)(d * p.c1) * 2u : OOB;
+                    pb0[j] = ok ? ctr0[j] + d0 : OOB;
+                    pb1[j] = ok ? ctr1[j] + d1 : OOB;
                 } else {                                                       // nearest-neighbour resize in front (Upsample2D)
-                    const int sy = (iy * p.h_in) / p.h_virt, sx = (ix * p.w_in) / p.w_virt;
-                    const int pix = (row_img[j] * p.h_in + sy) * p.w_in + sx;
+                    const RowCoords rc = row_coords(j);
+                    const int img = rc.img, iy = rc.iy, ix = rc.ix;
+                    const int sy = ((iy + dy) * p.h_in) / p.h_virt, sx = ((ix + dx) * p.w_in) / p.w_virt;
+                    const int pix = (img * p.h_in + sy) * p.w_in + sx;
                     const int rr = (wave + NW * j) * RPI + lrow;
                     const int slot8 = (lpos ^ ((rr / RPB) & swm)) * 8;
                     pb0[j] = ok ? (unsigned)(pix * p.c0 + slot8) * 2u : OOB;

@@ -42,6 +42,8 @@ __device__ __forceinline__ float wave_sum_halves(float x) {
 // Shader-clock timestamp (s_memtime) for the phase probe (AaConvGemm.debug bit 8).
 __device__ __forceinline__ long long clock_now() { return (long long)__builtin_amdgcn_s_memtime(); }
 
+__device__ __forceinline__ void idle_a_while() { __builtin_amdgcn_s_sleep(8); }
+
 // 64 zero bytes in device memory: what halo / tail lanes of an LDS-DMA tile load read instead of an activation.
 __device__ __attribute__((aligned(64))) u32x4 aa_zero_page_[4];
 __device__ __forceinline__ const void* zero_page() { return aa_zero_page_; }
@@ -62,6 +64,19 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) {
 }
 __device__ __forceinline__ void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r.v, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_offset, 0, 0, 0);
+}
+// 16-byte register loads / stores through a descriptor: out-of-range loads give zeros, out-of-range stores are dropped.
+__device__ __forceinline__ u32x4 buffer_load16(const BufRsrc& r, unsigned byte_offset) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.v, byte_offset, 0, 0));
+}
+__device__ __forceinline__ void buffer_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r.v, byte_offset, 0, 0);
+}
+// Order this wave's LDS accesses: everything before is complete (and visible to the wave's other lanes) before anything
+// after starts.  Enough to hand data between lanes of ONE wave through LDS - no workgroup barrier.
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 }
 // Index of this wavefront inside the workgroup, as a scalar.
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

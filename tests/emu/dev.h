@@ -194,7 +194,8 @@ inline f32x16 emu_mfma_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
 inline f32x16 mfma_32x32x16(f16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<f16_t>(a, b, c); }
 inline f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<bf16_t>(a, b, c); }
 
-inline long long clock_now() { return 0; }
+inline void idle_a_while() {}
+inline long long clock_now() { static long long t = 0; return t += 64; }
 inline const void* zero_page() { static const u32x4 z[4] = {}; return z; }
 inline void async_copy16(const void* gsrc, void* lds_wave_base) {
     std::memcpy(static_cast<char*>(lds_wave_base) + (emu::linear_tid() & 63) * 16, gsrc, 16);
@@ -207,7 +208,16 @@ inline void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_w
     if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(dst, r.base + byte_offset, 16);
     else std::memset(dst, 0, 16);
 }
+inline u32x4 buffer_load16(const BufRsrc& r, unsigned byte_offset) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(&v, r.base + byte_offset, 16);
+    return v;
+}
+inline void buffer_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
+    if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(const_cast<char*>(r.base) + byte_offset, &v, 16);
+}
 inline int wave_id() { return emu::linear_tid() >> 6; }
+inline void wave_lds_fence() { emu::wave_barrier(); }
 
 template <int N>
 inline void dma_wait() {}                       // the emulator's DMA is synchronous
