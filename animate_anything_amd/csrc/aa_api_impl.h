@@ -61,6 +61,9 @@ static const CgCfg kCgCfgs[] = {
     {64, 256, 2, 2, 32, 2, 3, 0.80f},     // 20
     {256, 320, 4, 2, 32, 4, 1, 1.20f},    // 21 staggered, deep ring
     {256, 256, 4, 2, 32, 4, 1, 1.20f},    // 22 staggered, deep ring
+    {192, 256, 2, 4, 64, 2, 1, 1.05f},    // 23 eight waves of 96x64: 230 tiles for the 8704-row (16x16) level = one 90 % round
+    {192, 256, 2, 4, 64, 2, 1, 1.05f},    // 24 staggered
+    {128, 256, 2, 4, 32, 2, 2, 1.00f},    // 25 eight waves of 64x64, two workgroups per CU
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -95,6 +98,7 @@ static int cg_splits(const AaConvGemm& d, int M, const CgCfg& c) {
     const int tiles = ((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
     const int slots = 256 * c.per_cu;
     const int nk = d.k_pad / c.bk;
+    if (d.k_splits >= 1) return d.k_splits <= nk ? d.k_splits : nk;      // the caller's (autotuned) choice
     if (tiles * 2 > slots || nk < 32) return 1;
     int s = slots / tiles;
     if (s > 8) s = 8;
@@ -145,6 +149,9 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 20: cg_launch_dma<T, 64, 256, 2, 2, 32, 2, 3>(d, m_begin, m_end, splits, stream); break;
         case 21: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1, true>(d, m_begin, m_end, splits, stream); break;
         case 22: cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1, true>(d, m_begin, m_end, splits, stream); break;
+        case 23: cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
+        case 24: cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1, true>(d, m_begin, m_end, splits, stream); break;
+        case 25: cg_launch_dma<T, 128, 256, 2, 4, 32, 2, 2>(d, m_begin, m_end, splits, stream); break;
         default: return false;
     }
     return true;

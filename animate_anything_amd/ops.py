@@ -28,49 +28,76 @@ TRACE = None
 # operands and the fastest index is remembered for that signature (descriptor field `tile`).
 AUTOTUNE = True
 LAST_STAMPS = None
+K_SPLITS = 0          # tests: explicit K split count for calls that are not autotuned (0 = library decides)
 DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
 # (BM, BN, BK, stages) - mirrors the table in csrc/aa_api_impl.h
 TILE_TABLE = ((128, 64, 64, 2), (128, 128, 64, 2), (192, 256, 64, 2), (256, 256, 64, 2), (256, 320, 64, 2), (192, 320, 64, 2),
               (256, 320, 32, 4), (256, 256, 32, 4), (128, 128, 32, 4), (128, 64, 32, 4), (192, 320, 32, 4),
-              (128, 320, 32, 2), (128, 256, 32, 2), (128, 256, 64, 2), (256, 320, 64, 2), (256, 256, 64, 2), (128, 128, 32, 2), (128, 64, 32, 2), (64, 128, 32, 2), (64, 64, 32, 2), (64, 256, 32, 2), (256, 320, 32, 4), (256, 256, 32, 4))
+              (128, 320, 32, 2), (128, 256, 32, 2), (128, 256, 64, 2), (256, 320, 64, 2), (256, 256, 64, 2), (128, 128, 32, 2), (128, 64, 32, 2), (64, 128, 32, 2), (64, 64, 32, 2), (64, 256, 32, 2), (256, 320, 32, 4), (256, 256, 32, 4), (192, 256, 64, 2), (192, 256, 64, 2), (128, 256, 32, 2))
 _tile_cache = {}
 
 
+TILE_PER_CU = (3, 2, 1, 1, 1, 1, 1, 1, 2, 3, 1, 2, 2, 1, 1, 1, 3, 4, 4, 6, 3, 1, 1, 1, 1, 2)
+TILE_WN = (2,) * 23 + (4, 4, 4)                                                                 # wave columns   # co-resident workgroups of each table entry
+
+
 def save_tile_cache(path):
-    """Persist the autotuned tile choices (json) so a later process can skip the tuning launches."""
+    """Persist the autotuned (tile, K splits) choices (json) so a later process can skip the tuning launches."""
     import json
     with open(path, "w") as f:
-        json.dump([[list(k), v] for k, v in _tile_cache.items()], f)
+        json.dump([[list(k), list(v)] for k, v in _tile_cache.items()], f)
 
 
 def load_tile_cache(path):
     import json
     with open(path) as f:
         for k, v in json.load(f):
-            _tile_cache[tuple(k)] = v
+            _tile_cache[tuple(k)] = tuple(v) if isinstance(v, (list, tuple)) else (v, 0)
 
 
-def _tile_candidates(d):
+def _tile_candidates(d, rows):
+    """(tile, k_splits) pairs worth timing: every tile shape that divides the packed width with the library's own split
+    decision (0), plus explicit K splits where they turn an under-filled single round of workgroups into (nearly)
+    full ones - the 16x16 / 8x8 levels, where 170 tiles of 256x256 would leave a third of the CUs idle."""
     dma = (d.c0 + d.c1) % 64 == 0 and d.c0 % 64 == 0 and d.out_dtype == d.dtype
     if not dma:
         return []
     out = []
-    for i, (bm, bn, _bk, _st) in enumerate(TILE_TABLE):
+    for i, (bm, bn, bk, _st) in enumerate(TILE_TABLE):
         if d.n_pad % bn:
             continue
-        if d.geglu and (bn // 2) % 64:                     # (every table entry has 2 wave columns)
+        if d.geglu and (bn // TILE_WN[i]) % 64:            # value / gate blocks pair up inside one wavefront
             continue
-        out.append(i)
+        out.append((i, 0))
+        if d.geglu or bm < 128:
+            continue
+        tiles = -(-rows // bm) * (d.n_pad // bn)
+        slots = 256 * TILE_PER_CU[i]
+        nk = d.k_pad // bk
+        if tiles >= slots:
+            continue
+        fill1 = tiles / slots
+        for sp in (2, 3, 4, 5, 6, 8):
+            if nk // sp < 8:
+                break
+            wgs = tiles * sp
+            fill = wgs / (-(-wgs // slots) * slots)
+            if wgs <= 3 * slots and fill >= 0.8 and fill > fill1 + 0.1:
+                out.append((i, sp))
     return out
 
 
-def _autotune(lib, d, stream, key):
-    cands = _tile_candidates(d)
-    best, best_t = -1, None
+def _autotune(lib, d, stream, key, rows, dev):
+    cands = _tile_candidates(d, rows)
+    best, best_t = (-1, 0), None
     if len(cands) > 1:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for c in cands:
-            d.tile = c
+        ws_keep = (d.workspace, d.workspace_bytes)
+        for c, sp in cands:
+            d.tile, d.k_splits = c, sp
+            need = lib.aa_conv_gemm_workspace(C.byref(d))
+            ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=dev)
+            d.workspace, d.workspace_bytes = C.c_void_p(ws.data_ptr()), need
             if lib.aa_conv_gemm(C.byref(d), stream) != 0:
                 continue
             # one launch per measurement, synchronised in between: back-to-back launches of one kernel overlap
@@ -84,7 +111,8 @@ def _autotune(lib, d, stream, key):
                 ts.append(e0.elapsed_time(e1))
             t = sorted(ts)[1]
             if best_t is None or t < best_t:
-                best, best_t = c, t
+                best, best_t = (c, sp), t
+        d.workspace, d.workspace_bytes = ws_keep
     _tile_cache[key] = best
     return best
 
@@ -260,14 +288,14 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.dtype, d.out_dtype, d.out_scale = _DT[x0.dtype], _DT[odt], out_scale
     d.k_order = pw.k_order
     d.debug = DEBUG_ABLATE
-    d.tile = -1
+    d.tile, d.k_splits = -1, K_SPLITS
     if AUTOTUNE and x0.is_cuda:
         key = (d.dtype, g.n_img, g.h_in, g.w_in, d.h_virt, d.w_virt, g.h_out, g.w_out, g.stride, pw.kh, pw.kw, c0, c1,
                pw.n_out, d.geglu, residual is not None)
-        tile = _tile_cache.get(key)
-        if tile is None and not torch.cuda.is_current_stream_capturing():
-            tile = _autotune(lib, d, _stream(x0), key)
-        d.tile = -1 if tile is None else tile
+        choice = _tile_cache.get(key)
+        if choice is None and not torch.cuda.is_current_stream_capturing():
+            choice = _autotune(lib, d, _stream(x0), key, g.rows, x0.device)
+        d.tile, d.k_splits = (-1, 0) if choice is None else choice
     ws = None
     need = lib.aa_conv_gemm_workspace(C.byref(d))        # split-K scratch for few-tile / long-K calls
     if DEBUG_ABLATE & 8:                                  # phase probe: [workgroup][8] shader-clock stamps

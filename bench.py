@@ -201,13 +201,13 @@ def main():
                 g_[0] += 1
                 g_[1] += ev0.elapsed_time(ev1) / 3
                 g_[2] += 2.0 * key[0] * key[1] * key[2]
-                g_[3] = d.tile
+                g_[3] = f"{d.tile}/{d.k_splits}" if d.k_splits else f"{d.tile}"
             with open(a.gemm_breakdown, "w") as f:
                 f.write("M K N kind flags | launches total_ms TFLOP/s tile share\n")
                 tot = sum(v[1] for v in groups.values())
                 for key, v in sorted(groups.items(), key=lambda kv: -kv[1][1]):
                     f.write(f"{key[0]:7d} {key[1]:6d} {key[2]:6d} {key[3]:6s} {key[4]:5s}{key[5]:3s} | {v[0]:3d} {v[1]:8.3f} "
-                            f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} {v[3]:3d} {v[1] / tot * 100:5.1f}%\n")
+                            f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} {v[3]:>4s} {v[1] / tot * 100:5.1f}%\n")
         ach = flops / (gemm_ms * 1e-3) / 1e12
         # HBM bytes per launch of the dominant kernel: PMC numbers (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # separate rocprofv3 passes, scripts/pmc_traffic.sh) committed under profiles/ - bench.py cannot run the

@@ -90,6 +90,8 @@ typedef struct AaConvGemm {
                               2 = skip the MFMA phase (results are garbage); 4 = size the
                               round-splitting heuristic for a 2-CU chip (exercises it on small test shapes) */
     int32_t tile;          /* -1: library picks the tile shape; >= 0: index into the tile table (autotuning) */
+    int32_t k_splits;      /* 0: library decides whether to split K; >= 1: this many K ranges (needs the workspace
+                              aa_conv_gemm_workspace reports for the same descriptor; ignored when not applicable) */
 } AaConvGemm;
 
 /* Bytes of fp32 scratch with which aa_conv_gemm would split the K loop of this call over several workgroups

@@ -243,7 +243,7 @@ def test_geglu_dma_path_wide(backend):
     close(y, (h[:, :D] * F.gelu(h[:, D:])).half().float() + r.float())
 
 
-@pytest.mark.parametrize("cfg,N", [(0, 320), (1, 640), (2, 256), (3, 256), (4, 640), (5, 320), (6, 320), (7, 512), (8, 128), (9, 64), (10, 640), (11, 320), (12, 256), (13, 512), (14, 320), (15, 256), (16, 128), (17, 64), (18, 128), (19, 64), (20, 256), (21, 320), (22, 256)])
+@pytest.mark.parametrize("cfg,N", [(0, 320), (1, 640), (2, 256), (3, 256), (4, 640), (5, 320), (6, 320), (7, 512), (8, 128), (9, 64), (10, 640), (11, 320), (12, 256), (13, 512), (14, 320), (15, 256), (16, 128), (17, 64), (18, 128), (19, 64), (20, 256), (21, 320), (22, 256), (23, 256), (24, 256), (25, 256)])
 def test_dma_tile_shapes(backend, cfg, N):
     """Every tile shape of the LDS-DMA kernel (forced), conv3x3 with halo + M tail + residual."""
     from animate_anything_amd import _lib
@@ -269,6 +269,42 @@ def test_geglu_wide_tiles(backend, D):
     assert pw.geglu == 32
     h = x.float() @ w.float().t() + b.float()
     close(ops.conv_gemm(x, pw, ops.linear_geom(M)), h[:, :D] * F.gelu(h[:, D:]))
+
+
+@pytest.mark.parametrize("cfg,splits", [(1, 3), (3, 5), (16, 2)])
+def test_explicit_k_splits(backend, cfg, splits):
+    """Caller-chosen K split count (autotuner): uneven K ranges, fp32 partials, reduce launch with the fused epilogue."""
+    from animate_anything_amd import _lib
+    n, h, w, cin, N = 2, 9, 11, 128, 256              # K = 1152 = 18 (36) K steps: 18 / 5 leaves an uneven last range
+    x, wt, b = rnd(n, cin, h, w, seed=91), rnd(N, cin, 3, 3, scale=0.05, seed=92), rnd(N, seed=93)
+    g = ops.conv3x3_geom(n, h, w)
+    res = rnd(g.rows, N, seed=94)
+    lib = _lib.get()
+    lib.aa_set_tile_override(cfg)
+    ops.K_SPLITS = splits
+    try:
+        y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res, act=ops.AA_ACT_SILU)
+    finally:
+        ops.K_SPLITS = 0
+        lib.aa_set_tile_override(-1)
+    ref = nhwc(F.silu(F.conv2d(x.float(), wt.float(), b.float(), padding=1))).half().float() + res.float()
+    close(y, ref)
+
+
+@pytest.mark.parametrize("cfg", [23, 25, 3])
+def test_geglu_forced_tiles(backend, cfg):
+    """GEGLU value/gate pairing inside one wavefront for the 4-wave-column tiles (NI = 2) and the 2-column ones (NI = 4)."""
+    from animate_anything_amd import _lib
+    M, K, D = 300, 128, 384
+    x, w, b = rnd(M, K, seed=95), rnd(2 * D, K, scale=0.1, seed=96), rnd(2 * D, seed=97)
+    lib = _lib.get()
+    lib.aa_set_tile_override(cfg)
+    try:
+        y = ops.conv_gemm(x, ops.pack_weight(w, b, geglu=True), ops.linear_geom(M))
+    finally:
+        lib.aa_set_tile_override(-1)
+    h = x.float() @ w.float().t() + b.float()
+    close(y, h[:, :D] * F.gelu(h[:, D:]))
 
 
 def test_sparse_last_round_is_split_to_small_tiles(backend):
