@@ -325,6 +325,10 @@ int aa_attention(const AaAttention* d, void* stream) {
         if (!aligned16(x->ptr) || x->ld % 8 || x->col0 % 8) return fail(AA_E_ALIGN, "attention: operand rows must be 16-byte aligned");
         if (x->outer_div <= 0) return fail(AA_E_SHAPE, "attention: outer_div must be >= 1");
     }
+    // K / V are read through buffer descriptors with 32-bit byte offsets; offsets >= 2^31 mean "zero"
+    if (attn_extent_bytes(d->k, d->n_outer, d->n_inner, d->kv_len) >= ((int64_t)1 << 31) ||
+        attn_extent_bytes(d->v, d->n_outer, d->n_inner, d->kv_len) >= ((int64_t)1 << 31))
+        return fail(AA_E_SHAPE, "attention: K / V operand must stay below 2 GiB");
     if (d->dtype == AA_F16) return attention_t<f16_t>(*d, stream);
     if (d->dtype == AA_BF16) return attention_t<bf16_t>(*d, stream);
     return fail(AA_E_DTYPE, "attention: unsupported dtype %d", d->dtype);

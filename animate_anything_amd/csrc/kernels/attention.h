@@ -1,15 +1,20 @@
 // Flash-style attention for gfx950, head_dim 64 (see include/aa_mi355.h: aa_attention).
 //
 // One wavefront owns 32 query rows of one (sequence, head); NW wavefronts of a workgroup share each
-// 64-key K/V tile through LDS (double buffered, one barrier per tile, next tile's global loads in flight
-// during the current tile's math).  The score tile is computed TRANSPOSED, S^T = K Q^T, so that in the
-// 32x32 MFMA result layout (col = lane&31) every lane owns one query row: the online-softmax max and
-// sum are register-local (one xor-32 shuffle joins the two half-waves), and the exponentiated
-// registers are, unchanged, the B operand of O^T = V^T P^T.
-// V is written to LDS transposed, [d][key], with (a) the keys permuted inside each 16-key chunk (quads 1
-// and 2 swapped) so the matching A operand is a single ds_read_b128, and (b) the 8-key chunks of row d
-// XOR-ed with x(d) = ((d>>3) + 2*(d&7)) & 7, which makes both the 2-byte transposing stores and the
-// 16-byte fragment reads bank-conflict free on the unpadded 128-byte rows.
+// 64-key K/V tile through a ring of LDS buffers.  The score tile is computed TRANSPOSED, S^T = K Q^T, so that in
+// the 32x32 MFMA result layout (col = lane&31) every lane owns one query row: the online-softmax max and sum are
+// register-local (one v_permlane32_swap joins the two half-waves), and the exponentiated registers are,
+// unchanged, the B operand of O^T = V^T P^T.
+//
+// K and V tiles travel HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds` (LDS-DMA: no VGPR staging, no ds_write,
+// keys past kv_len are out of range of the descriptor and arrive as zeros).  The DMA deposits lane-linear 16-byte
+// pieces, so the layouts are made on the SOURCE side (which piece each lane fetches):
+//  * K: row-major [key][64 d], 128-byte rows, the 16-byte d-slots XOR-swizzled with (key>>1)&7 - the A fragment of
+//    S^T (row = key, 8 consecutive d) is one conflict-free ds_read_b128;
+//  * V: stays ROW-major (no transposing stores): 256-byte blocks [4 keys][32 d], block index (key/4, d/32).  The A
+//    fragment of O^T needs, for row d, 8 consecutive keys - a column of V - which gfx950's transposing LDS read
+//    delivers directly: one `ds_read_b64_tr_b16` hands lane l of a 16-lane group V[k0..k0+3][d0 + l] from a
+//    [4 keys][16 d] block; a 32-lane half reads exactly one 256-byte block = all 64 banks once.
 // Softmax runs in base 2: p = exp2(s*c - m*c), c = scale*log2(e), max taken on raw scores.
 #pragma once
 #include "dev.h"
@@ -17,29 +22,36 @@
 
 namespace aa {
 
-constexpr int AT_KT = 64;       // keys per tile
-constexpr int AT_LDK = 72;      // padded K row (elements)
-constexpr int AT_LDV = 64;      // V^T row (elements), XOR-swizzled instead of padded
-constexpr int AT_BUF = AT_KT * AT_LDK + 64 * AT_LDV;    // elements per (K, V^T) buffer pair
+constexpr int AT_KT = 64;                       // keys per tile
+constexpr int AT_TILE_BYTES = 2 * AT_KT * 128;  // K tile + V tile of one stage
 
-// one (K, V^T) buffer when the sequence fits a single tile (temporal / text attention), else two
-__host__ __device__ inline int attn_lds_bytes(int kv_len) { return (kv_len > AT_KT ? 2 : 1) * AT_BUF * 2; }
+// ring depth: one buffer when the sequence fits a single tile (temporal / text attention), else three
+__host__ __device__ inline int attn_stages(int kv_len) { return kv_len > AT_KT ? 3 : 1; }
+__host__ __device__ inline int attn_lds_bytes(int kv_len) { return attn_stages(kv_len) * AT_TILE_BYTES; }
 
+// first token row of sequence (o, i), in rows of the operand's matrix
+__device__ __forceinline__ int64_t attn_seq_row(const AaAttnOperand& x, int o, int i) {
+    return (int64_t)(o / x.outer_div) * x.outer_stride + (int64_t)i * x.inner_stride;
+}
 template <typename T>
 __device__ __forceinline__ const T* attn_row(const AaAttnOperand& x, int o, int i, int pos, int head) {
-    const int64_t row = (int64_t)(o / x.outer_div) * x.outer_stride + (int64_t)i * x.inner_stride + (int64_t)pos * x.pos_stride;
-    return reinterpret_cast<const T*>(x.ptr) + row * x.ld + x.col0 + head * 64;
+    return reinterpret_cast<const T*>(x.ptr) + (attn_seq_row(x, o, i) + (int64_t)pos * x.pos_stride) * x.ld + x.col0 + head * 64;
 }
-
-__device__ __forceinline__ int vt_swz(int d) { return ((d >> 3) + 2 * (d & 7)) & 7; }
+// bytes of the operand an attention call may touch (descriptor range)
+__host__ __device__ inline int64_t attn_extent_bytes(const AaAttnOperand& x, int n_outer, int n_inner, int len) {
+    const int64_t last = (int64_t)((n_outer - 1) / x.outer_div) * x.outer_stride + (int64_t)(n_inner - 1) * x.inner_stride +
+                         (int64_t)(len - 1) * x.pos_stride;
+    return (last + 1) * x.ld * 2;
+}
 
 template <typename T, int NW>
 __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(const AaAttention p) {
-    constexpr int THREADS = 64 * NW;
-    constexpr int SLOTS = (AT_KT * 8) / THREADS;     // 16-byte K (and V) slots staged per thread
-    T* lds = reinterpret_cast<T*>(dyn_smem());
+    constexpr int PER = 16 / NW;                 // DMA instructions per wave and tile (8 for K + 8 for V in total)
+    constexpr unsigned OOB = 0x80000000u;
+    char* lds = dyn_smem();
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id();
     const int h = lane >> 5, ql = lane & 31;
     const int head = blockIdx.y;
     const int seq = blockIdx.z;
@@ -62,48 +74,43 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
         }
     }
 
-    // per-slot K / V source pointers of tile 0, advanced by one tile (64 keys) per fetch: no 64-bit row
-    // arithmetic in the loop
-    u32x4 rk[SLOTS], rv[SLOTS];
-    const T* kptr[SLOTS];
-    const T* vptr[SLOTS];
+    // ---- K / V tile DMA: instruction `n` (0..7) of a tile covers keys 8n .. 8n+7 of K (or V); wave w issues
+    // instructions w*PER/2 .. of each.  Per lane: key and byte offset inside the row, fixed for the whole kernel.
+    const BufRsrc r_k = make_rsrc(p.k.ptr, (unsigned)attn_extent_bytes(p.k, p.n_outer, p.n_inner, p.kv_len));
+    const BufRsrc r_v = make_rsrc(p.v.ptr, (unsigned)attn_extent_bytes(p.v, p.n_outer, p.n_inner, p.kv_len));
+    const unsigned k_seq = (unsigned)((attn_seq_row(p.k, o, i) * p.k.ld + p.k.col0 + head * 64) * 2);
+    const unsigned v_seq = (unsigned)((attn_seq_row(p.v, o, i) * p.v.ld + p.v.col0 + head * 64) * 2);
+    const unsigned k_key = (unsigned)(p.k.pos_stride * p.k.ld * 2), v_key = (unsigned)(p.v.pos_stride * p.v.ld * 2);   // bytes per key
+    // K piece of this lane: key (lane>>3) of the instruction, d-slot (lane&7) ^ swizzle(key row inside the tile)
+    const int kk = lane >> 3;
+    // V piece: 256-byte block b = lane>>4 -> (key group b>>1, d half b&1); inside: key%4 = (lane>>2)&3, d-slot lane&3
+    const int vk = 4 * (lane >> 5) + ((lane >> 2) & 3), vd = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+    // per-lane offsets of tile 0, advanced by one tile (64 keys) per issue: no multiplies in the loop
+    unsigned koff[PER / 2], voff[PER / 2];
+    int klocal[PER / 2], vlocal[PER / 2];
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int sl = tid + s * THREADS;
-        kptr[s] = attn_row<T>(p.k, o, i, sl >> 3, head) + (sl & 7) * 8;
-        vptr[s] = attn_row<T>(p.v, o, i, sl >> 3, head) + (sl & 7) * 8;
+    for (int j = 0; j < PER / 2; ++j) {
+        const int n = wave * (PER / 2) + j;
+        klocal[j] = 8 * n + kk;
+        vlocal[j] = 8 * n + vk;
+        koff[j] = k_seq + (unsigned)klocal[j] * k_key + (unsigned)(((lane & 7) ^ ((klocal[j] >> 1) & 7)) * 16);
+        voff[j] = v_seq + (unsigned)vlocal[j] * v_key + (unsigned)(vd * 2);
     }
-    const int64_t k_step = (int64_t)AT_KT * p.k.pos_stride * p.k.ld, v_step = (int64_t)AT_KT * p.v.pos_stride * p.v.ld;
-    auto fetch = [&](int kt) {
+    int next_tile_key0 = 0;                      // issue() is called for consecutive tiles
+    auto issue = [&](int buf) {
+        char* sK = lds + buf * AT_TILE_BYTES;
+        char* sV = sK + AT_KT * 128;
+        const int rem = p.kv_len - next_tile_key0;                        // keys left from this tile on
+        next_tile_key0 += AT_KT;
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int sl = tid + s * THREADS;
-            const bool ok = kt * AT_KT + (sl >> 3) < p.kv_len;
-            u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
-            if (ok) {
-                a = *reinterpret_cast<const u32x4*>(kptr[s]);
-                b = *reinterpret_cast<const u32x4*>(vptr[s]);
-            }
-            rk[s] = a; rv[s] = b;
-            kptr[s] += k_step; vptr[s] += v_step;
+        for (int j = 0; j < PER / 2; ++j) {
+            async_copy16_buf(r_k, klocal[j] < rem ? koff[j] : OOB, sK + (wave * (PER / 2) + j) * 1024);
+            koff[j] += AT_KT * k_key;
         }
-    };
-    auto stash = [&](int buf) {
-        T* sK = lds + buf * AT_BUF;
-        T* sVt = sK + AT_KT * AT_LDK;
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int sl = tid + s * THREADS;
-            const int key = sl >> 3, dseg = sl & 7;
-            *reinterpret_cast<u32x4*>(sK + key * AT_LDK + dseg * 8) = rk[s];
-            const int quad = (key >> 2) & 3;
-            const int pos = (key & ~15) | ((((quad & 1) << 1) | (quad >> 1)) << 2) | (key & 3);
-            Pack8<T> v; v.raw = rv[s];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = dseg * 8 + e;
-                sVt[d * AT_LDV + (pos ^ (vt_swz(d) << 3))] = v.e[e];
-            }
+        for (int j = 0; j < PER / 2; ++j) {
+            async_copy16_buf(r_v, vlocal[j] < rem ? voff[j] : OOB, sV + (wave * (PER / 2) + j) * 1024);
+            voff[j] += AT_KT * v_key;
         }
     };
 
@@ -114,26 +121,30 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
 
     const int ntiles = (p.kv_len + AT_KT - 1) / AT_KT;
     const bool ragged = (p.kv_len & (AT_KT - 1)) != 0;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    constexpr bool PREFETCH = NW > 1;    // one-wave workgroups stage 8 slots per thread: keep those registers free
+    const int stages = attn_stages(p.kv_len);   // 3 (two tiles in flight ahead of the math) or 1 (single tile)
+    issue(0);
+    if (ntiles > 1) issue(1);
+    // fragment read offsets inside a stage (bytes)
+    const int kf_row = ql * 128, kf_swz = (ql >> 1) & 7;                  // + kb*32 rows: (32*kb + ql)>>1 & 7 == (ql>>1)&7
+    const int vf_off = (2 * h) * 256 + ((lane & 15) >> 2) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     for (int kt = 0; kt < ntiles; ++kt) {
-        if (PREFETCH && kt + 1 < ntiles) fetch(kt + 1);
+        if (kt + 1 < ntiles) dma_wait<PER>(); else dma_wait<0>();         // tile kt landed (Q fragments are older still)
+        block_barrier();                                                  // everyone's pieces; buffer (kt-1)%3 is free again
+        if (kt + 2 < ntiles) issue((kt + 2) % 3);
         if (wave_active) {
-            const T* sK = lds + (kt & 1) * AT_BUF;
-            const T* sVt = sK + AT_KT * AT_LDK;
+            const char* sK = lds + (stages == 1 ? 0 : (kt % 3)) * AT_TILE_BYTES;
+            const char* sV = sK + AT_KT * 128;
             f32x16 sacc[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int e = 0; e < 16; ++e) { sacc[0][e] = 0.0f; sacc[1][e] = 0.0f; }
+            // the two 32-key blocks alternate so that consecutive MFMAs never wait on each other's accumulator
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.0f;
+            for (int dk = 0; dk < 4; ++dk)
 #pragma unroll
-                for (int dk = 0; dk < 4; ++dk) {
-                    const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + (32 * kb + ql) * AT_LDK + 16 * dk + 8 * h);
+                for (int kb = 0; kb < 2; ++kb) {
+                    const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + kb * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
                     sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], sacc[kb]);
                 }
-            }
             if (ragged && kt == ntiles - 1) {           // mask the keys past kv_len (last tile only)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -183,20 +194,18 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
             const f32x2 pst = (ps2[0] + ps2[1]) + (ps2[2] + ps2[3]);
             const float psum = pst[0] + pst[1];
             l_run += psum;
+            // O^T += V^T P^T: chunk ch = 16 keys; this half-wave's 8 k-slots are keys 16ch + 4h + {0..3} and
+            // 16ch + 8 + 4h + {0..3} (the order P^T's registers came out of the S^T accumulator layout)
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+            for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
-                    const int d = 32 * db + ql;
-                    const u32x4 vf = *reinterpret_cast<const u32x4*>(sVt + d * AT_LDV + (((2 * ch + h) ^ vt_swz(d)) << 3));
+                for (int db = 0; db < 2; ++db) {
+                    const char* base = sV + (2 * ch) * 1024 + db * 256 + vf_off;
+                    const u32x2 lo = lds_read_tr16_b64(base), hi = lds_read_tr16_b64(base + 1024);
+                    const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
                     oacc[db] = mfma_32x32x16(T(), vf, pf[ch], oacc[db]);
                 }
         }
-        if (kt + 1 < ntiles) {
-            if (!PREFETCH) fetch(kt + 1);
-            stash((kt + 1) & 1);
-        }
-        __syncthreads();
     }
 
     if (wave_active) {

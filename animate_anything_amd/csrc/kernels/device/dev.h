@@ -72,6 +72,14 @@ __device__ __forceinline__ u32x4 buffer_load16(const BufRsrc& r, unsigned byte_o
 __device__ __forceinline__ void buffer_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r.v, byte_offset, 0, 0);
 }
+// Transposing LDS read (ds_read_b64_tr_b16): every lane passes the address of 4 consecutive 16-bit elements; inside
+// each 16-lane group, lane l = 4a + b receives element b of lanes a, 4 + a, 8 + a, 12 + a.  With lane s pointing at
+// row (s>>2), columns 4(s&3).. of a row-major [4][16] block, lane l gets column l of the block, rows 0..3.
+__device__ __forceinline__ u32x2 lds_read_tr16_b64(const void* lds_ptr) {
+    typedef short s16x4_ __attribute__((ext_vector_type(4)));
+    const auto v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(lds_ptr));
+    return __builtin_bit_cast(u32x2, v);
+}
 // Order this wave's LDS accesses: everything before is complete (and visible to the wave's other lanes) before anything
 // after starts.  Enough to hand data between lanes of ONE wave through LDS - no workgroup barrier.
 __device__ __forceinline__ void wave_lds_fence() {

@@ -218,6 +218,20 @@ inline void buffer_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
 }
 inline int wave_id() { return emu::linear_tid() >> 6; }
 inline void wave_lds_fence() { emu::wave_barrier(); }
+inline u32x2 lds_read_tr16_b64(const void* lds_ptr) {
+    unsigned short r[4] = {0, 0, 0, 0};
+    emu::wave_collective(&lds_ptr, [&](const std::vector<const void*>& s) {
+        const int l = emu::linear_tid() & 63, g = l & ~15, a = (l & 15) >> 2, b = l & 3;
+        for (int j = 0; j < 4; ++j) {
+            const void* src = *static_cast<const void* const*>(s[g + 4 * j + a]);
+            r[j] = static_cast<const unsigned short*>(src)[b];
+        }
+    });
+    u32x2 out;
+    out[0] = (unsigned)r[0] | ((unsigned)r[1] << 16);
+    out[1] = (unsigned)r[2] | ((unsigned)r[3] << 16);
+    return out;
+}
 
 template <int N>
 inline void dma_wait() {}                       // the emulator's DMA is synchronous

@@ -156,6 +156,18 @@ def test_attention_spatial(backend):
     close(o, ref, tol=1e-2)
 
 
+@pytest.mark.parametrize("Lq,Lkv", [(300, 300), (50, 200), (130, 64)])
+def test_attention_ring(backend, Lq, Lkv):
+    """Several K/V tiles through the 3-slot LDS ring (4-wave and 1-wave workgroups), ragged last tile, single tile."""
+    n, heads = 2, 1
+    q = rnd(n * Lq, 64, seed=38)
+    kv = rnd(n * Lkv, 128, seed=39)
+    o = ops.attention(q, 0, kv, 0, kv, 64, heads, n, 1, Lq, Lkv, (Lq, 0, 1), (Lkv, 0, 1))
+    kk = kv.reshape(n, Lkv, 2, 64)
+    ref = sdpa(q.reshape(n, 1, Lq, 64), kk[:, :, 0].reshape(n, 1, Lkv, 64), kk[:, :, 1].reshape(n, 1, Lkv, 64)).reshape(n * Lq, 64)
+    close(o, ref, tol=1e-2)
+
+
 def test_attention_cross_text(backend):
     clips, frames, heads, L, Lt = 2, 2, 1, 40, 77
     C = heads * 64
