@@ -244,9 +244,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     // (hipcc keeps ONE set and waits lgkmcnt(0) each sub-step) - for shapes whose accumulators leave no room.
     auto frag_ptr_a = [&](const char* st, int ks, int i) { return st + a_off[i] + (((ks * 2 + fh) ^ a_swz[i]) << 4); };
     auto frag_ptr_b = [&](const char* st, int ks, int j) { return st + b_off[j] + (((ks * 2 + fh) ^ b_swz[j]) << 4); };
-    auto compute = [&](int buf) {
+    constexpr int KS = BK / 16;
+    // multiply K tile `buf`; before sub-step `issue_at` the wave issues its DMA share of tile `kt_next` (if any)
+    auto compute = [&](int buf, int issue_at, int kt_next, bool more) {
         const char* st = smem + buf * STAGE_BYTES;
-        constexpr int KS = BK / 16;
         if constexpr (FRAG_ASM) {
             u32x4 fa[2][MI], fb[2][NI];
             auto issue_frags = [&](int ks, int set) {
@@ -259,6 +260,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int set = ks & 1;
+                if (more && ks == issue_at) issue(kt_next, kt_next % STAGES);
                 if (ks + 1 < KS) { issue_frags(ks + 1, set ^ 1); lds_wait<MI + NI>(fa[set][0]); }
                 else lds_wait<0>(fa[set][0]);
 #pragma unroll
@@ -273,6 +275,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         } else {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+                if (more && ks == issue_at) issue(kt_next, kt_next % STAGES);
                 u32x4 fa[MI], fb[NI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const u32x4*>(frag_ptr_a(st, ks, i));
@@ -309,14 +312,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             AA_TICK(0)
             block_barrier();                 // everyone's share of tile kt landed; buffer (kt-1)%STAGES is free
             AA_TICK(1)
-            // STAGGER: the second wave of every SIMD (waves NW/2..) multiplies first and issues afterwards, its partner the
-            // other way round: a SIMD then always has one wave feeding the matrix pipe while the other sits in the (CU-wide,
+            // STAGGER: the second wave of every SIMD (waves NW/2..) issues its DMA share in the MIDDLE of its multiply (the
+            // data still has half a K step to land), its partner before its own: a SIMD then always has one wave feeding the matrix pipe while the other sits in the (CU-wide,
             // ~20 clk per instruction) LDS-DMA issue queue - instead of eight waves queueing there together.
-            const bool mult_first = STAGGER && wave >= NW / 2;
-            if (mult_first && !(p.debug & 2)) compute(kt % STAGES);
-            if (kt + DIST < nk && !(p.debug & 1)) issue(kt + DIST, (kt + DIST) % STAGES);
-            AA_TICK(2)
-            if (!mult_first && !(p.debug & 2)) compute(kt % STAGES);
+            int issue_at = (STAGGER && wave >= NW / 2) ? KS / 2 : 0;
+            if (STAGGER && (p.debug & 0x1000)) issue_at = (wave >= NW / 2) ? (p.debug >> 10) & 3 : (p.debug >> 8) & 3;   // probe: issue points
+            const bool more = kt + DIST < nk && !(p.debug & 1);
+            if (!(p.debug & 2)) compute(kt % STAGES, issue_at, kt + DIST, more);
+            else if (more) issue(kt + DIST, (kt + DIST) % STAGES);
             AA_TICK(3)
         }
     }

@@ -54,15 +54,9 @@ def probe(name, fn, cfgs):
 M = 34 * 64 * 64
 x320 = rnd(M, 320)
 res = rnd(M, 320)
-w = ops.pack_weight(rnd(960, 320), rnd(960))
-probe("linear qkv K=320 N=960", lambda: ops.conv_gemm(x320, w, ops.linear_geom(M)), [4, 14])
-w = ops.pack_weight(rnd(320, 320), rnd(320))
-probe("linear C->C K=320 N=320 +res", lambda: ops.conv_gemm(x320, w, ops.linear_geom(M), residual=res), [4, 14, 17])
 x1280 = rnd(M, 1280)
 w = ops.pack_weight(rnd(320, 1280), rnd(320))
 probe("linear ff2 K=1280 N=320 +res", lambda: ops.conv_gemm(x1280, w, ops.linear_geom(M), residual=res), [4, 14])
-w = ops.pack_weight(rnd(2560, 320), rnd(2560), geglu=True)
-probe("geglu K=320 N=2560", lambda: ops.conv_gemm(x320, w, ops.linear_geom(M)), [3, 15, 22])
 w = ops.pack_weight(rnd(320, 320, 3, 3), rnd(320))
 probe("conv3x3 320->320", lambda: ops.conv_gemm(x320, w, ops.conv3x3_geom(34, 64, 64)), [4, 14, 6, 21])
 M2 = 34 * 32 * 32
@@ -72,4 +66,6 @@ probe("conv3x3 640->640", lambda: ops.conv_gemm(x640, w, ops.conv3x3_geom(34, 32
 M3 = 34 * 16 * 16
 x1 = rnd(M3, 1280)
 w = ops.pack_weight(rnd(1280, 1280), rnd(1280))
-probe("linear K=1280 N=1280 M=8704", lambda: ops.conv_gemm(x1, w, ops.linear_geom(M3)), [3, 15, 22, 1])
+probe("linear K=1280 N=1280 M=8704", lambda: ops.conv_gemm(x1, w, ops.linear_geom(M3)), [3, 15, 23, 24])
+w = ops.pack_weight(rnd(1280, 1280, 3, 3), rnd(1280))
+probe("conv3x3 1280 M=8704", lambda: ops.conv_gemm(x1, w, ops.conv3x3_geom(34, 16, 16)), [3, 15, 23, 24])
