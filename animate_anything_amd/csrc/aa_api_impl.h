@@ -308,10 +308,14 @@ int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y, in
     using namespace aa;
     if (rows <= 0 || channels <= 0 || channels % 8 || channels > 2048) return fail(AA_E_SHAPE, "layernorm: rows=%lld channels=%d", (long long)rows, channels);
     if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta)) return fail(AA_E_ALIGN, "layernorm: operands must be 16-byte aligned");
-    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (dtype == AA_F16) AA_LAUNCH((layernorm_kernel<f16_t>), grid, block, 0, stream, (const f16_t*)x, (const f16_t*)gamma, (const f16_t*)beta, (f16_t*)y, rows, channels, eps);
-    else if (dtype == AA_BF16) AA_LAUNCH((layernorm_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, rows, channels, eps);
-    else return fail(AA_E_DTYPE, "layernorm: unsupported dtype %d", dtype);
+    const int sj = channels <= 512 ? 1 : (channels <= 1024 ? 2 : 4);      // 16-byte slots per lane and row
+    const int per_wg = 4 * (4 / sj);                                        // rows per workgroup (4 waves)
+    const dim3 grid((unsigned)((rows + per_wg - 1) / per_wg)), block(256);
+    if (dtype != AA_F16 && dtype != AA_BF16) return fail(AA_E_DTYPE, "layernorm: unsupported dtype %d", dtype);
+#define AA_LN(T, SJ) AA_LAUNCH((layernorm_kernel<T, SJ>), grid, block, 0, stream, (const T*)x, (const T*)gamma, (const T*)beta, (T*)y, rows, channels, eps)
+    if (dtype == AA_F16) { if (sj == 1) AA_LN(f16_t, 1); else if (sj == 2) AA_LN(f16_t, 2); else AA_LN(f16_t, 4); }
+    else                 { if (sj == 1) AA_LN(bf16_t, 1); else if (sj == 2) AA_LN(bf16_t, 2); else AA_LN(bf16_t, 4); }
+#undef AA_LN
     return finish("layernorm");
 }
 

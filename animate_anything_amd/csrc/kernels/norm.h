@@ -187,46 +187,62 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_apply_kernel(const AaGro
     }
 }
 
-// ---- LayerNorm: one wavefront per row, the row lives in registers (C <= 2048), two-pass variance.
-template <typename T>
+// ---- LayerNorm: a wavefront owns LN_ROWS<SJ> rows at a time, the rows live in registers (C <= 2048), two-pass variance.
+// SJ = 16-byte slots per lane and row (C <= 512 * SJ); narrow rows are processed several at once so that every wave
+// keeps four independent 16-byte loads in flight (a 640-byte row per wave leaves HBM latency exposed).
+template <typename T, int SJ>
 __global__ void __launch_bounds__(256) layernorm_kernel(const T* x, const T* gamma, const T* beta, T* y,
                                                        int64_t rows, int C, float eps) {
+    constexpr int R = 4 / SJ;                               // rows per wave
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
     const int S = C >> 3;
-    Pack8<T> v[4];
-    float sum = 0.0f;
+    Pack8<T> v[R][SJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < SJ; ++j) {
+            const int slot = lane + 64 * j;
+            v[r][j].raw = u32x4{0u, 0u, 0u, 0u};
+            if (slot < S && row0 + r < rows) v[r][j].raw = *reinterpret_cast<const u32x4*>(x + (row0 + r) * C + slot * 8);
+        }
+    Pack8<T> g[SJ], b[SJ];
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) {
         const int slot = lane + 64 * j;
+        g[j].raw = u32x4{0u, 0u, 0u, 0u}; b[j].raw = u32x4{0u, 0u, 0u, 0u};
         if (slot < S) {
-            v[j].raw = *reinterpret_cast<const u32x4*>(x + row * C + slot * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += (float)v[j].e[e];
+            g[j].raw = *reinterpret_cast<const u32x4*>(gamma + slot * 8);
+            b[j].raw = *reinterpret_cast<const u32x4*>(beta + slot * 8);
         }
     }
-    const float mean = wave_sum(sum) / (float)C;
-    float sq = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int slot = lane + 64 * j;
-        if (slot < S) {
+    for (int r = 0; r < R; ++r) {
+        if (row0 + r >= rows) break;
+        float sum = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = (float)v[j].e[e] - mean; sq += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+        for (int j = 0; j < SJ; ++j)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int slot = lane + 64 * j;
-        if (slot < S) {
-            Pack8<T> g, b, o;
-            g.raw = *reinterpret_cast<const u32x4*>(gamma + slot * 8);
-            b.raw = *reinterpret_cast<const u32x4*>(beta + slot * 8);
+            for (int e = 0; e < 8; ++e) sum += (float)v[r][j].e[e];          // (slots past the row hold zeros)
+        const float mean = wave_sum(sum) / (float)C;
+        float sq = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o.e[e] = (T)(((float)v[j].e[e] - mean) * rstd * (float)g.e[e] + (float)b.e[e]);
-            *reinterpret_cast<u32x4*>(y + row * C + slot * 8) = o.raw;
+        for (int j = 0; j < SJ; ++j)
+            if (lane + 64 * j < S) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)v[r][j].e[e] - mean; sq += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+        for (int j = 0; j < SJ; ++j) {
+            const int slot = lane + 64 * j;
+            if (slot < S) {
+                Pack8<T> o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.e[e] = (T)(((float)v[r][j].e[e] - mean) * rstd * (float)g[j].e[e] + (float)b[j].e[e]);
+                *reinterpret_cast<u32x4*>(y + (row0 + r) * C + slot * 8) = o.raw;
+            }
         }
     }
 }

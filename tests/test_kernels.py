@@ -135,9 +135,9 @@ def test_groupnorm(backend, c0, c1, groups, frames):
     close(y, ref)
 
 
-@pytest.mark.parametrize("C", [64, 320, 1280])
+@pytest.mark.parametrize("C", [64, 320, 640, 1280])
 def test_layernorm(backend, C):
-    x, g, b = rnd(10, C, seed=28) * 3 + 1, rnd(C, seed=29), rnd(C, seed=30)
+    x, g, b = rnd(11, C, seed=28) * 3 + 1, rnd(C, seed=29), rnd(C, seed=30)
     close(ops.layernorm(x, g, b, 1e-5), F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5))
 
 
