@@ -11,13 +11,14 @@
 //  * requires the K tile to sit inside one filter tap and one concat source ((c0+c1) % 64 == 0 and
 //    c0 % 64 == 0): tap / source / channel base are then wave-uniform scalars and the per-row pixel offsets
 //    are recomputed only when the tap changes;
-//  * pipeline: STAGES-1 tiles are in flight ahead of the one being multiplied.  The measured limiter of the
-//    2-stage version is the DMA round trip under load (~1.5-2.5 us against a ~1.2 us MFMA phase), so the
-//    deeper rings wait with a COUNTED `s_waitcnt vmcnt(n)` (only the oldest tile must have landed) and a raw
-//    `s_barrier` (a __syncthreads() would drain every DMA); one barrier per K step;
-//  * epilogue: bias / time-embedding row vector / SiLU in registers, tile parked in LDS as storage dtype
-//    (one accumulator block-row of every wave at a time), read back row-major so GEGLU pairing (value | gate
-//    halves of the tile), residual loads and output stores are full 16-byte, row-contiguous.
+//  * pipeline: STAGES-1 tiles are in flight ahead of the one being multiplied; the rings wait with a COUNTED
+//    `s_waitcnt vmcnt(n)` (only the oldest tile must have landed) and a raw `s_barrier` (a __syncthreads() would
+//    drain every DMA); one barrier per K step.  STAGGER variants let the second wave of every SIMD issue its DMA
+//    share in the middle of its multiply, so the CU-wide DMA issue queue never holds all eight waves at once;
+//  * the MFMA runs "transposed" (weights = A operand, rows permuted), which leaves 16 consecutive output columns
+//    of one row in each lane's accumulator registers: the epilogue (bias from an LDS slice, time-embedding row
+//    vector, SiLU, GEGLU value*gelu(gate) inside one lane, residual, scale) needs no LDS transpose and no
+//    barrier and stores 16-byte pieces straight from registers.
 #pragma once
 #include "dev.h"
 #include "aa_mi355.h"

@@ -65,13 +65,6 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) {
 __device__ __forceinline__ void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r.v, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_offset, 0, 0, 0);
 }
-// 16-byte register loads / stores through a descriptor: out-of-range loads give zeros, out-of-range stores are dropped.
-__device__ __forceinline__ u32x4 buffer_load16(const BufRsrc& r, unsigned byte_offset) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.v, byte_offset, 0, 0));
-}
-__device__ __forceinline__ void buffer_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r.v, byte_offset, 0, 0);
-}
 // Transposing LDS read (ds_read_b64_tr_b16): every lane passes the address of 4 consecutive 16-bit elements; inside
 // each 16-lane group, lane l = 4a + b receives element b of lanes a, 4 + a, 8 + a, 12 + a.  With lane s pointing at
 // row (s>>2), columns 4(s&3).. of a row-major [4][16] block, lane l gets column l of the block, rows 0..3.
@@ -79,12 +72,6 @@ __device__ __forceinline__ u32x2 lds_read_tr16_b64(const void* lds_ptr) {
     typedef short s16x4_ __attribute__((ext_vector_type(4)));
     const auto v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(lds_ptr));
     return __builtin_bit_cast(u32x2, v);
-}
-// Order this wave's LDS accesses: everything before is complete (and visible to the wave's other lanes) before anything
-// after starts.  Enough to hand data between lanes of ONE wave through LDS - no workgroup barrier.
-__device__ __forceinline__ void wave_lds_fence() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
 }
 // Index of this wavefront inside the workgroup, as a scalar.
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

@@ -16,7 +16,6 @@ p.add_argument("--dtype", default="fp16")
 p.add_argument("--only", default="")
 p.add_argument("--reps", type=int, default=10)
 p.add_argument("--ablate", type=int, default=0, help="AaConvGemm.debug ablation bits (1: no DMA, 2: no MFMA)")
-p.add_argument("--geglu-gran", type=int, default=0)
 p.add_argument("--cfg-sweep", action="store_true", help="time every contraction shape under every forced tile shape")
 a = p.parse_args()
 DT = torch.float16 if a.dtype == "fp16" else torch.bfloat16
@@ -44,7 +43,6 @@ from animate_anything_amd import _lib  # noqa: E402
 CFGS = list(ops.TILE_TABLE)
 ops.AUTOTUNE = False
 ops.DEBUG_ABLATE = a.ablate
-ops.GEGLU_GRAN = a.geglu_gran
 
 
 def sweep(name, fn, flops, n_pad, geglu=0):

@@ -208,16 +208,7 @@ inline void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_w
     if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(dst, r.base + byte_offset, 16);
     else std::memset(dst, 0, 16);
 }
-inline u32x4 buffer_load16(const BufRsrc& r, unsigned byte_offset) {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(&v, r.base + byte_offset, 16);
-    return v;
-}
-inline void buffer_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
-    if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(const_cast<char*>(r.base) + byte_offset, &v, 16);
-}
 inline int wave_id() { return emu::linear_tid() >> 6; }
-inline void wave_lds_fence() { emu::wave_barrier(); }
 inline u32x2 lds_read_tr16_b64(const void* lds_ptr) {
     unsigned short r[4] = {0, 0, 0, 0};
     emu::wave_collective(&lds_ptr, [&](const std::vector<const void*>& s) {
