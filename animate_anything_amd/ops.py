@@ -28,6 +28,7 @@ TRACE = None
 # operands and the fastest index is remembered for that signature (descriptor field `tile`).
 AUTOTUNE = True
 LAST_STAMPS = None
+MAX_OPERAND_BYTES = 1 << 31      # the contraction kernel's 32-bit operand offsets
 K_SPLITS = 0          # tests: explicit K split count for calls that are not autotuned (0 = library decides)
 DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
 # (BM, BN, BK, stages) - mirrors the table in csrc/aa_api_impl.h
@@ -272,6 +273,29 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     _check(x0, x1, pw.w, b, rowvec, residual, out)
     c0 = x0.shape[-1]
     c1 = 0 if x1 is None else x1.shape[-1]
+    # The LDS-DMA kernel addresses every operand with 32-bit byte offsets (< 2 GiB).  Bigger activations (the VAE above
+    # 512x512 x 16 frames) are cut along the image axis - images are independent rows of the implicit GEMM.
+    n_cols_ = pw.n_out // 2 if pw.geglu else pw.n_out
+    in_rows = g.n_img * g.h_in * g.w_in
+    biggest = 2 * max(in_rows * max(c0, c1), g.rows * max(n_cols_ if out is None else out.stride(0),
+                                                          0 if residual is None else residual.stride(0)))
+    if biggest >= MAX_OPERAND_BYTES and g.n_img > 1 and not bias_per_row:
+        if out is None:
+            out = torch.empty(g.rows, n_cols_, dtype=x0.dtype if out_dtype is None else out_dtype, device=x0.device)
+        parts = min(g.n_img, -(-biggest // (MAX_OPERAND_BYTES // 2)))
+        per = -(-g.n_img // parts)
+        ri, ro = g.h_in * g.w_in, g.h_out * g.w_out
+        for i0 in range(0, g.n_img, per):
+            n = min(per, g.n_img - i0)
+            gi = Geom(n, g.h_in, g.w_in, g.h_out, g.w_out, g.stride, g.pad_h, g.pad_w, g.h_virt, g.w_virt)
+            rv = rowvec
+            if rowvec is not None:                         # row-vector groups are whole images (or whole clips of them)
+                assert (i0 * ro) % rowvec_div == 0 and ((i0 + n) * ro) % rowvec_div == 0 or i0 + n == g.n_img
+                rv = rowvec[(i0 * ro) // rowvec_div:]
+            conv_gemm(x0[i0 * ri:(i0 + n) * ri], pw, gi, None if x1 is None else x1[i0 * ri:(i0 + n) * ri], rv, rowvec_div,
+                      None if residual is None else residual[i0 * ro:(i0 + n) * ro], act, out_dtype, out_scale, False,
+                      out[i0 * ro:(i0 + n) * ro], bias)
+        return out
     if c0 + c1 != pw.cin:
         raise RuntimeError(f"conv_gemm: activation has {c0}+{c1} channels, weight expects {pw.cin}")
     n_cols = pw.n_out // 2 if pw.geglu else pw.n_out

@@ -319,6 +319,18 @@ def test_geglu_forced_tiles(backend, cfg):
     close(y, h[:, :D] * F.gelu(h[:, D:]))
 
 
+def test_big_operands_are_cut_along_the_image_axis(backend, monkeypatch):
+    """Activations beyond the kernel's 32-bit operand offsets are processed image group by image group."""
+    n, h, w, cin, N = 5, 6, 7, 64, 64
+    x, wt, b = rnd(n, cin, h, w, seed=101), rnd(N, cin, 3, 3, scale=0.05, seed=102), rnd(N, seed=103)
+    g = ops.conv3x3_geom(n, h, w)
+    res, temb = rnd(g.rows, N, seed=104), rnd(n, N, seed=105)
+    monkeypatch.setattr(ops, "MAX_OPERAND_BYTES", 2 * 2 * h * w * cin + 1)       # two images per call at most
+    y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res, rowvec=temb, rowvec_div=h * w)
+    ref = nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1) + temb.float()[:, :, None, None]).half().float() + res.float()
+    close(y, ref)
+
+
 def test_sparse_last_round_is_split_to_small_tiles(backend):
     """Big-tile launches hand a sparsely filled last round of tiles to a small-tile launch (m_begin path)."""
     from animate_anything_amd import _lib
