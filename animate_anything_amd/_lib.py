@@ -62,7 +62,7 @@ class AaDpmStep(C.Structure):
     ]
 
 
-SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_groupnorm_workspace", "aa_groupnorm",
+SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_groupnorm_workspace", "aa_groupnorm",
            "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step")
 
 DEFAULT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaa_mi355.so")
@@ -81,6 +81,8 @@ def bind(path: str) -> C.CDLL:
     lib.aa_last_error.restype = C.c_char_p
     lib.aa_set_tile_override.argtypes = [C.c_int]
     lib.aa_set_tile_override.restype = None
+    lib.aa_conv_gemm_tile_info.argtypes = [C.c_int, C.POINTER(C.c_int32)]
+    lib.aa_conv_gemm_tile_info.restype = C.c_int
     lib.aa_conv_gemm.argtypes = [C.POINTER(AaConvGemm), C.c_void_p]
     lib.aa_conv_gemm_workspace.argtypes = [C.POINTER(AaConvGemm)]
     lib.aa_conv_gemm_workspace.restype = C.c_size_t
@@ -92,7 +94,7 @@ def bind(path: str) -> C.CDLL:
     lib.aa_attention.argtypes = [C.POINTER(AaAttention), C.c_void_p]
     lib.aa_softmax_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.aa_cfg_dpm_step.argtypes = [C.POINTER(AaDpmStep), C.c_void_p]
-    for s in SYMBOLS[3:]:
+    for s in SYMBOLS[4:]:
         if s not in ("aa_groupnorm_workspace", "aa_conv_gemm_workspace"):
             getattr(lib, s).restype = C.c_int
     return lib

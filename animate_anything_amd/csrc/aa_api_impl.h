@@ -250,6 +250,12 @@ static int attention_t(const AaAttention& d, void* stream) {
 extern "C" {
 
 int aa_version(void) { return AA_VERSION; }
+int aa_conv_gemm_tile_info(int idx, int32_t info[7]) {
+    if (idx < 0 || idx >= aa::kNumCgCfgs || !info) return -1;
+    const aa::CgCfg& c = aa::kCgCfgs[idx];
+    info[0] = c.bm; info[1] = c.bn; info[2] = c.wm; info[3] = c.wn; info[4] = c.bk; info[5] = c.stages; info[6] = c.per_cu;
+    return 0;
+}
 void aa_set_tile_override(int cfg) { aa::g_tile_override = cfg < 0 ? -1 : cfg; }
 const char* aa_last_error(void) { return aa::g_err; }
 

@@ -32,9 +32,38 @@ MAX_OPERAND_BYTES = 1 << 31      # the contraction kernel's 32-bit operand offse
 K_SPLITS = 0          # tests: explicit K split count for calls that are not autotuned (0 = library decides)
 DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
 # (BM, BN, BK, stages) - mirrors the table in csrc/aa_api_impl.h
-TILE_TABLE = ((128, 64, 64, 2), (128, 128, 64, 2), (192, 256, 64, 2), (256, 256, 64, 2), (256, 320, 64, 2), (192, 320, 64, 2),
-              (256, 320, 32, 4), (256, 256, 32, 4), (128, 128, 32, 4), (128, 64, 32, 4), (192, 320, 32, 4),
-              (128, 320, 32, 2), (128, 256, 32, 2), (128, 256, 64, 2), (256, 320, 64, 2), (256, 256, 64, 2), (128, 128, 32, 2), (128, 64, 32, 2), (64, 128, 32, 2), (64, 64, 32, 2), (64, 256, 32, 2), (256, 320, 32, 4), (256, 256, 32, 4), (192, 256, 64, 2), (192, 256, 64, 2), (128, 256, 32, 2))
+class _TileTable:
+    """The library's tile table (aa_conv_gemm_tile_info), read on first use: entries (rows, columns, K step, stages)."""
+
+    def __init__(self):
+        self._rows = None
+
+    def _load(self):
+        if self._rows is None:
+            lib, rows, info = _lib.get(), [], (C.c_int32 * 7)()
+            while lib.aa_conv_gemm_tile_info(len(rows), info) == 0:
+                rows.append(tuple(info))
+            self._rows = rows
+        return self._rows
+
+    def __iter__(self):
+        return iter([(r[0], r[1], r[4], r[5]) for r in self._load()])
+
+    def __len__(self):
+        return len(self._load())
+
+    def __getitem__(self, i):
+        r = self._load()[i]
+        return (r[0], r[1], r[4], r[5])
+
+    def wave_cols(self, i):
+        return self._load()[i][3]
+
+    def per_cu(self, i):
+        return self._load()[i][6]
+
+
+TILE_TABLE = _TileTable()
 _tile_cache = {}
 
 
@@ -67,13 +96,13 @@ def _tile_candidates(d, rows):
     for i, (bm, bn, bk, _st) in enumerate(TILE_TABLE):
         if d.n_pad % bn:
             continue
-        if d.geglu and (bn // TILE_WN[i]) % 64:            # value / gate blocks pair up inside one wavefront
+        if d.geglu and (bn // TILE_TABLE.wave_cols(i)) % 64:            # value / gate blocks pair up inside one wavefront
             continue
         out.append((i, 0))
         if d.geglu or bm < 128:
             continue
         tiles = -(-rows // bm) * (d.n_pad // bn)
-        slots = 256 * TILE_PER_CU[i]
+        slots = 256 * TILE_TABLE.per_cu(i)
         nk = d.k_pad // bk
         if tiles >= slots:
             continue

@@ -99,6 +99,10 @@ typedef struct AaConvGemm {
 size_t aa_conv_gemm_workspace(const AaConvGemm* d);
 int aa_conv_gemm(const AaConvGemm* d, void* stream);
 
+/* Tile table of the LDS-DMA contraction kernel (what `AaConvGemm.tile` indexes): fills info[0..6] = rows, columns, wave
+ * rows, wave columns, K step, ring stages, workgroups per CU of entry `idx`; returns 0, or -1 past the end of the table. */
+int aa_conv_gemm_tile_info(int idx, int32_t info[7]);
+
 /* Tuning / test aid: force tile shape `cfg` (index into the table in csrc/aa_api_impl.h) for every
  * following aa_conv_gemm call whose packed width it divides; cfg < 0 restores the automatic choice. */
 void aa_set_tile_override(int cfg);

@@ -52,7 +52,7 @@ def sweep(name, fn, flops, n_pad, geglu=0):
     if not a.cfg_sweep:
         return
     for i, (bm, bn, bk, st) in enumerate(CFGS):
-        if n_pad % bn or (geglu and (bn // ops.TILE_WN[i]) % 64):
+        if n_pad % bn or (geglu and (bn // ops.TILE_TABLE.wave_cols(i)) % 64):
             continue
         lib.aa_set_tile_override(i)
         report(f"{name} [{i}:{bm}x{bn} k{bk} s{st}]", timeit(fn), flops=flops)
