@@ -98,7 +98,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const BufRsrc r_a0 = make_rsrc(p.a0, (unsigned)((int64_t)p.n_img * p.h_in * p.w_in * p.c0 * 2));
     const BufRsrc r_a1 = make_rsrc(p.a1, p.c1 ? (unsigned)((int64_t)p.n_img * p.h_in * p.w_in * p.c1 * 2) : 0u);
     const BufRsrc r_w = make_rsrc(p.w, (unsigned)((int64_t)p.n_pad * p.k_pad * 2));
-    const int swm = (p.debug & 16) ? 0 : SPR - 1;        // debug bit 16: no XOR swizzle (probe: LDS bank conflicts of the fragment reads)
+#ifdef AA_PHASE_PROBE
+    const int swm = (p.debug & 16) ? 0 : SPR - 1;        // probe build, debug bit 16: no XOR swizzle (LDS bank conflicts of the fragment reads)
+    const bool dry = p.debug & 32;                       // probe build, debug bit 32: every DMA piece out of range (issue cost without memory traffic)
+#else
+    constexpr int swm = SPR - 1;
+    constexpr bool dry = false;
+#endif
+    const bool two_src = p.c1 != 0;                      // channel-concatenated input (up blocks): a second offset set
     const int lrow = lane / SPR, lpos = lane % SPR;
     // per fed activation row: byte offset of its top-left tap pixel (+ this lane's swizzled k-slot) in a0 / a1, and which
     // taps read a real pixel: bits 0..7 = rows dy inside the image, bits 8..15 = columns dx (0 for rows outside the tile)
@@ -186,7 +193,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
                 const bool ok = tap < taps && (((vmask[j] >> dy) & (vmask[j] >> (8 + dx))) & 1u);
                 if (!resize) {
                     pb0[j] = ok ? ctr0[j] + d0 : OOB;
-                    pb1[j] = ok ? ctr1[j] + d1 : OOB;
+                    if (two_src) pb1[j] = ok ? ctr1[j] + d1 : OOB;
                 } else {                                                       // nearest-neighbour resize in front (Upsample2D)
                     const RowCoords rc = row_coords(j);
                     const int img = rc.img, iy = rc.iy, ix = rc.ix;
@@ -204,7 +211,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         const BufRsrc ra = src1 ? r_a1 : r_a0;
         char* a = smem + buf * STAGE_BYTES + wave * RPI * ROWB;
         char* b = smem + buf * STAGE_BYTES + BM * ROWB + wave * RPI * ROWB;
-        const bool dry = p.debug & 32;                   // debug bit 32: every piece is out of range (issue cost without memory traffic)
         // every wave issues exactly PER_TILE instructions (vmcnt bookkeeping): groups past the tile edge read
         // out of range and land in the dummy zone (wave-uniform choice)
 #pragma unroll
