@@ -186,19 +186,30 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         }
         if (tap != cur_tap) {
             cur_tap = tap;
-            const int d = dy * p.w_in + dx;
-            const unsigned d0 = (unsigned)(d * p.c0) * 2u, d1 = (unsigned)(d * p.c1) * 2u;
+            const bool tap_ok = tap < taps;
+            if (!resize) {                                     // (branches hoisted out of the per-row loops)
+                const int d = dy * p.w_in + dx;
+                const unsigned d0 = (unsigned)(d * p.c0) * 2u;
 #pragma unroll
-            for (int j = 0; j < AJ; ++j) {
-                const bool ok = tap < taps && (((vmask[j] >> dy) & (vmask[j] >> (8 + dx))) & 1u);
-                if (!resize) {
+                for (int j = 0; j < AJ; ++j) {
+                    const bool ok = tap_ok && (((vmask[j] >> dy) & (vmask[j] >> (8 + dx))) & 1u);
                     pb0[j] = ok ? ctr0[j] + d0 : OOB;
-                    if (two_src) pb1[j] = ok ? ctr1[j] + d1 : OOB;
-                } else {                                                       // nearest-neighbour resize in front (Upsample2D)
+                }
+                if (two_src) {
+                    const unsigned d1 = (unsigned)(d * p.c1) * 2u;
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) {
+                        const bool ok = tap_ok && (((vmask[j] >> dy) & (vmask[j] >> (8 + dx))) & 1u);
+                        pb1[j] = ok ? ctr1[j] + d1 : OOB;
+                    }
+                }
+            } else {                                           // nearest-neighbour resize in front (Upsample2D)
+#pragma unroll
+                for (int j = 0; j < AJ; ++j) {
+                    const bool ok = tap_ok && (((vmask[j] >> dy) & (vmask[j] >> (8 + dx))) & 1u);
                     const RowCoords rc = row_coords(j);
-                    const int img = rc.img, iy = rc.iy, ix = rc.ix;
-                    const int sy = ((iy + dy) * p.h_in) / p.h_virt, sx = ((ix + dx) * p.w_in) / p.w_virt;
-                    const int pix = (img * p.h_in + sy) * p.w_in + sx;
+                    const int sy = ((rc.iy + dy) * p.h_in) / p.h_virt, sx = ((rc.ix + dx) * p.w_in) / p.w_virt;
+                    const int pix = (rc.img * p.h_in + sy) * p.w_in + sx;
                     const int rr = (wave + NW * j) * RPI + lrow;
                     const int slot8 = (lpos ^ ((rr / RPB) & swm)) * 8;
                     pb0[j] = ok ? (unsigned)(pix * p.c0 + slot8) * 2u : OOB;
