@@ -26,7 +26,7 @@ class AaConvGemm(C.Structure):
         ("n_out", C.c_int32), ("n_pad", C.c_int32), ("k_pad", C.c_int32),
         ("rowvec_div", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
         ("act", C.c_int32), ("geglu", C.c_int32), ("bias_per_row", C.c_int32),
-        ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("k_order", C.c_int32), ("debug", C.c_int32), ("tile", C.c_int32), ("k_splits", C.c_int32),
+        ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("k_order", C.c_int32), ("debug", C.c_int32), ("tile", C.c_int32), ("k_splits", C.c_int32), ("rowvec_ld", C.c_int32),
     ]
 
 

@@ -279,6 +279,7 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream) {
         return fail(AA_E_SHAPE, "conv_gemm: bad packed extents n_pad=%d k_pad=%d (K=%d, n_out=%d)", d->n_pad, d->k_pad, d->kh * d->kw * ctot, d->n_out);
     if (d->n_img <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->rowvec_div <= 0)
         return fail(AA_E_SHAPE, "conv_gemm: bad geometry");
+    if (d->rowvec_ld < 0 || d->rowvec_ld % 8 || (d->rowvec_ld && d->rowvec_ld < d->n_out)) return fail(AA_E_SHAPE, "conv_gemm: rowvec_ld=%d must be 0 or a multiple of 8 >= n_out", d->rowvec_ld);
     if (d->geglu && (d->geglu != 32 || d->n_out != d->n_pad || d->bias_per_row))
         return fail(AA_E_SHAPE, "conv_gemm: GEGLU packs (32 value | 32 gate) column blocks, n_out == n_pad (geglu=%d n_out=%d)", d->geglu, d->n_out);
     if ((int64_t)d->n_img * d->h_out * d->w_out >= (int64_t)1 << 31) return fail(AA_E_SHAPE, "conv_gemm: M overflows int32");

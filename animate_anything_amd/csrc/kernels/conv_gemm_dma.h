@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         const bool m_ok = m < M;
         const int mc = m_ok ? m : M - 1;
         const float brow = (p.bias_per_row && bias) ? (float)bias[mc] : 0.0f;
-        const T* rv = rowvec ? rowvec + (int64_t)(mc / p.rowvec_div) * p.n_out : nullptr;
+        const T* rv = rowvec ? rowvec + (int64_t)(mc / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out) : nullptr;
         const T* rs = resid ? resid + (int64_t)mc * p.ldr : nullptr;
         // one block-row of row-vector (or residual) pieces is fetched up front so their latency overlaps
         u32x4 pre[NI][2];
@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const AaConvGemm p, 
         for (int e = 0; e < 8; ++e) {
             float x = v[e];
             if (bias) x += (float)bias[p.bias_per_row ? m : n + e];
-            if (rowvec) x += (float)rowvec[(int64_t)(m / p.rowvec_div) * p.n_out + n + e];
+            if (rowvec) x += (float)rowvec[(int64_t)(m / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out) + n + e];
             if (p.act == AA_ACT_SILU) x = silu_f(x);
             x = (float)(T)x;                                       // same rounding point as the fused epilogue
             if (resid) x += (float)resid[(int64_t)m * p.ldr + n + e];

@@ -152,12 +152,15 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = Conv2d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
         self.output_scale_factor = output_scale_factor
+        self.tproj = None        # this block's slice of a batched time-embedding projection (set by the UNet per forward)
 
     def tokens(self, x, g: Grid, temb_silu=None, x1=None):
         geom = ops.conv3x3_geom(g.images, g.h, g.w)
         h = self.norm1.tokens(x, g.images, g.hw, silu=True, x1=x1)
         if self.time_emb_proj is not None and temb_silu is not None:
-            tproj = self.time_emb_proj.tokens(temb_silu)                    # [clips, Cout]
+            # [clips, Cout]: normally a column slice of ONE projection of all the blocks' time embeddings
+            tproj = self.tproj if self.tproj is not None else self.time_emb_proj.tokens(temb_silu)
+            self.tproj = None
             h = self.conv1.tokens(h, geom, rowvec=tproj, rowvec_div=g.frames * g.hw)
         else:
             h = self.conv1.tokens(h, geom)

@@ -299,7 +299,10 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
               bias: Optional[torch.Tensor] = "packed") -> torch.Tensor:
     lib = _lib.get()
     b = pw.bias if isinstance(bias, str) else bias
-    _check(x0, x1, pw.w, b, rowvec, residual, out)
+    _check(x0, x1, pw.w, b, residual, out)
+    if rowvec is not None:                                 # may be a column slice of a wider matrix (row pitch = stride(0))
+        if (not rowvec.is_cuda and not _lib.host_pointers_ok()) or rowvec.stride(-1) != 1:
+            raise RuntimeError("conv_gemm: rowvec must be a GPU tensor with contiguous rows")
     c0 = x0.shape[-1]
     c1 = 0 if x1 is None else x1.shape[-1]
     # The LDS-DMA kernel addresses every operand with 32-bit byte offsets (< 2 GiB).  Bigger activations (the VAE above
@@ -341,6 +344,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.kh, d.kw, d.stride, d.pad_h, d.pad_w = pw.kh, pw.kw, g.stride, g.pad_h, g.pad_w
     d.n_out, d.n_pad, d.k_pad = pw.n_out, pw.n_pad, pw.k_pad
     d.rowvec_div = rowvec_div
+    d.rowvec_ld = 0 if rowvec is None or rowvec.dim() < 2 else rowvec.stride(0)
     d.ldo = out.stride(0)
     d.ldr = 0 if residual is None else residual.stride(0)
     d.act, d.geglu, d.bias_per_row = act, int(pw.geglu), int(bias_per_row)

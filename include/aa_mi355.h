@@ -92,6 +92,7 @@ typedef struct AaConvGemm {
     int32_t tile;          /* -1: library picks the tile shape; >= 0: index into the tile table (autotuning) */
     int32_t k_splits;      /* 0: library decides whether to split K; >= 1: this many K ranges (needs the workspace
                               aa_conv_gemm_workspace reports for the same descriptor; ignored when not applicable) */
+    int32_t rowvec_ld;     /* row pitch of `rowvec` in elements (a slice of a wider matrix); 0 = n_out */
 } AaConvGemm;
 
 /* Bytes of fp32 scratch with which aa_conv_gemm would split the K loop of this call over several workgroups

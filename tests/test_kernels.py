@@ -331,6 +331,18 @@ def test_big_operands_are_cut_along_the_image_axis(backend, monkeypatch):
     close(y, ref)
 
 
+def test_rowvec_is_a_column_slice_of_a_wider_matrix(backend):
+    """Time-embedding row vector passed as a view into a batched projection (row pitch != n_out)."""
+    n, h, w, cin, N = 4, 5, 6, 64, 64
+    x, wt, b = rnd(n, cin, h, w, seed=121), rnd(N, cin, 3, 3, scale=0.05, seed=122), rnd(N, seed=123)
+    wide = rnd(2, 3 * N + 64, seed=124)                    # [clips, many blocks' projections]
+    temb = wide[:, N:2 * N]
+    g = ops.conv3x3_geom(n, h, w)
+    y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, rowvec=temb, rowvec_div=2 * h * w)
+    ref = F.conv2d(x.float(), wt.float(), b.float(), padding=1) + temb.float().repeat_interleave(2, 0)[:, :, None, None]
+    close(y, nhwc(ref))
+
+
 def test_sparse_last_round_is_split_to_small_tiles(backend):
     """Big-tile launches hand a sparsely filled last round of tiles to a small-tile launch (m_begin path)."""
     from animate_anything_amd import _lib
