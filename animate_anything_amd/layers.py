@@ -242,6 +242,7 @@ class Attention(nn.Module):
         self.to_v = Linear(kv_dim, inner, bias=False)
         self.to_out = nn.ModuleList([Linear(inner, query_dim), nn.Dropout(0.0)])
         self._fused = None
+        self.kv = None
 
     def _apply(self, fn, *a, **k):
         self._fused = None
@@ -255,7 +256,11 @@ class Attention(nn.Module):
         return self._fused
 
     def text_kv(self, text_tokens):
-        """[clips*L, cross_dim] -> [clips*L, 2*inner] (K | V)."""
+        """[clips*L, cross_dim] -> [clips*L, 2*inner] (K | V): normally a column slice of ONE projection of the text for
+        all cross-attention layers of the network (`kv` set by the UNet per forward)."""
+        if self.kv is not None:
+            kv, self.kv = self.kv, None
+            return kv
         return ops.conv_gemm(text_tokens, self.fused(), ops.linear_geom(text_tokens.shape[0]))
 
     def self_tokens(self, normed, residual, g: Grid, temporal: bool):

@@ -417,7 +417,9 @@ def attention(q: torch.Tensor, q_col0: int, k: torch.Tensor, k_col0: int, v: tor
     """softmax(q k^T * scale) v for every (outer, inner, head).  `*_strides` = (outer, inner, pos)
     row strides of the token matrices; output rows use the q addressing, columns [0, heads*64)."""
     lib = _lib.get()
-    _check(q, k, v)
+    for t in (q, k, v):                                   # operands may be column slices of wider matrices (ld = stride(0))
+        if (not t.is_cuda and not _lib.host_pointers_ok()) or t.stride(-1) != 1:
+            raise RuntimeError("attention: operands must be GPU tensors with contiguous rows")
     out = torch.empty(q.shape[0], heads * 64, dtype=q.dtype, device=q.device)
     d = AaAttention()
     d.q = _operand(q, q_col0, *q_strides)

@@ -236,7 +236,24 @@ class UNet3DConditionModel(nn.Module):
     def _apply(self, fn, *a, **k):
         self._graph = None
         self._temb_pack = None
+        self._text_pack = None
         return super()._apply(fn, *a, **k)
+
+    def _project_text(self, text_tokens):
+        """K | V of the text for every cross-attention layer as ONE contraction; each layer receives its column slice."""
+        from .layers import Attention
+        if getattr(self, "_text_pack", None) is None:
+            layers_ = [m for m in self.modules() if isinstance(m, Attention) and m.is_cross]
+            w = torch.cat([torch.cat([a.to_k.weight.detach(), a.to_v.weight.detach()], dim=0) for a in layers_], dim=0)
+            offs, o = [], 0
+            for a in layers_:
+                offs.append(o)
+                o += 2 * a.inner
+            self._text_pack = (ops.pack_weight(w), layers_, offs)
+        pw, layers_, offs = self._text_pack
+        proj = ops.conv_gemm(text_tokens, pw, ops.linear_geom(text_tokens.shape[0]))       # [clips*L, sum of 2*inner]
+        for a, o in zip(layers_, offs):
+            a.kv = proj[:, o:o + 2 * a.inner]
 
     def _project_time_embeddings(self, temb_silu):
         """All ResnetBlock2D.time_emb_proj of the network as ONE contraction (31 two-row GEMMs otherwise, each a
@@ -306,6 +323,7 @@ class UNet3DConditionModel(nn.Module):
         x8: [tokens, 8] input latents (+mask) zero-padded to 8 channels; returns [tokens, out_channels]."""
         temb_silu = self.time_embedding.tokens(t_sin, cond_sin, final_silu=True)       # [clips, 4*ch0]
         self._project_time_embeddings(temb_silu)
+        self._project_text(text_tokens)
         conv_in = self.conv_in2 if use_mask else self.conv_in
         x = conv_in.tokens(x8, ops.conv3x3_geom(g.images, g.h, g.w))
         if g.frames > 1:
