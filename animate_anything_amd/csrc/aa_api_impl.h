@@ -116,6 +116,57 @@ static bool cg_dma_ok(const AaConvGemm& d) {
            (int64_t)d.n_pad * d.k_pad * 2 < ((int64_t)1 << 31);
 }
 
+// How one aa_conv_gemm call is carried out on the LDS-DMA path (shared by aa_conv_gemm_workspace and the launcher).
+struct CgPlan {
+    int cfg;            // tile table index
+    int splits;         // > 1: the whole call is split along K (fp32 partials + reduce)
+    int m_main;         // rows [0, m_main) run with `cfg` in full residency rounds
+    int tail_cfg;       // rows [m_main, M): tile table index ...
+    int tail_splits;    // ... and K split count (> 1: big tile, partials of the tail rows only)
+    size_t workspace;   // bytes of fp32 scratch the plan needs (0: none)
+};
+
+static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) {
+    CgPlan p = {cg_choose(d, M), 1, M, -1, 1, 0};
+    if (p.cfg < 0) return p;
+    const CgCfg& c = kCgCfgs[p.cfg];
+    const bool probe = (d.debug & 8) != 0;               // phase probe: the workspace holds time stamps, one plain launch
+    if (probe) return p;
+    p.splits = have_workspace_or_query ? cg_splits(d, M, c) : 1;
+    if (p.splits > 1) { p.workspace = (size_t)p.splits * M * d.n_pad * 4; return p; }
+    p.splits = 1;
+    // One-workgroup-per-CU tiles run in lock-step rounds of 256; a sparsely filled last round wastes most of the chip.
+    // Split it off: full rounds with the big tile; the remaining rows either with the same tile split along K (long K:
+    // the leftover tiles x splits fill the chip for nk / splits steps) or with a small (2-3 per CU) tile.
+    if (c.per_cu != 1) return p;
+    const int tiles_n = d.n_pad / c.bn;
+    const int tiles_m = (M + c.bm - 1) / c.bm;
+    const int cus = (d.debug & 4) ? 2 : 256;              // debug bit 4: pretend a 2-CU chip (exercises the split in tests)
+    const int rounds = tiles_m * tiles_n / cus;
+    const int rem = tiles_m * tiles_n - rounds * cus;
+    if (!(rounds >= 1 && rem > 0 && rem * 8 < cus * 5)) return p;
+    p.m_main = (rounds * cus / tiles_n) * c.bm;
+    if (p.m_main >= M) { p.m_main = M; return p; }
+    const int nk = d.k_pad / c.bk;
+    const int tail_tiles = ((M - p.m_main + c.bm - 1) / c.bm) * tiles_n;
+    int ts = cus / tail_tiles;                            // workgroups available per leftover tile
+    if (ts > 4) ts = 4;                                   // (each split costs a round trip of fp32 partials)
+    if (ts > nk / 24) ts = nk / 24;                       // measured: K loops of <= 45 steps are better off with small tiles
+    if (have_workspace_or_query && ts >= 2 && !d.geglu) {
+        p.tail_cfg = p.cfg;
+        p.tail_splits = ts;
+        p.workspace = (size_t)ts * (M - p.m_main) * d.n_pad * 4;
+        return p;
+    }
+    const int small[2] = {1, 0};
+    for (int k = 0; k < 2 && p.tail_cfg < 0; ++k) {
+        const CgCfg& t = kCgCfgs[small[k]];
+        if (d.n_pad % t.bn == 0 && (!d.geglu || (t.bn / t.wn) % 64 == 0)) p.tail_cfg = small[k];
+    }
+    if (p.tail_cfg < 0) p.tail_cfg = p.cfg;               // no small tile fits (wide GEGLU): big tile again
+    return p;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER = false>
 static void cg_launch_dma(const AaConvGemm& d, int m_begin, int m_end, int splits, void* stream) {
     const int tiles_n = d.n_pad / BN;
@@ -162,42 +213,25 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
     const int M = (int)((int64_t)d.n_img * d.h_out * d.w_out);
     // LDS-DMA fast path: K tiles never straddle a filter tap / concat source, output rows are 16-byte chunks
     if (cg_dma_ok(d)) {
-        const int cfg = cg_choose(d, M);
-        if (cfg < 0) return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
-        const bool probe = (d.debug & 8) != 0;               // phase probe: the workspace holds time stamps, one plain launch
-        const int splits = probe ? 1 : cg_splits(d, M, kCgCfgs[cfg]);
-        if (splits > 1 && d.workspace && d.workspace_bytes >= (int64_t)splits * M * d.n_pad * 4) {
-            cg_launch_cfg<T>(cfg, d, 0, M, stream, splits);
-            int64_t blocks = ((int64_t)M * (d.n_out / 8) + 255) / 256;
+        CgPlan pl = cg_plan(d, M, d.workspace != nullptr);
+        if (pl.cfg < 0) return fail(AA_E_SHAPE, "conv_gemm: no tile shape divides n_pad=%d (geglu=%d)", d.n_pad, d.geglu);
+        if (pl.workspace > (size_t)d.workspace_bytes) pl = cg_plan(d, M, false);       // scratch too small: plan without it
+        auto reduce = [&](int m_begin, int splits) {
+            int64_t blocks = ((int64_t)(M - m_begin) * (d.n_out / 8) + 255) / 256;
             if (blocks > 4096) blocks = 4096;
-            AA_LAUNCH((splitk_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, d, M, splits);
+            AA_LAUNCH((splitk_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, d, M, m_begin, splits);
+        };
+        if (pl.splits > 1) {
+            cg_launch_cfg<T>(pl.cfg, d, 0, M, stream, pl.splits);
+            reduce(0, pl.splits);
             return finish("conv_gemm");
         }
-        // One-workgroup-per-CU tiles run in lock-step rounds of 256; a sparsely filled last round wastes most of
-        // the chip.  Split it off: full rounds with the big tile, the remaining rows with a small (2-3 per CU) tile.
-        const CgCfg& c = kCgCfgs[cfg];
-        int m_main = M;
-        if (c.per_cu == 1 && !probe) {
-            const int tiles_n = d.n_pad / c.bn;
-            const int tiles_m = (M + c.bm - 1) / c.bm;
-            const int cus = (d.debug & 4) ? 2 : 256;          // debug bit 4: pretend a 2-CU chip (exercises the split in tests)
-            const int rounds = tiles_m * tiles_n / cus;
-            const int rem = tiles_m * tiles_n - rounds * cus;
-            if (rounds >= 1 && rem > 0 && rem * 8 < cus * 5) m_main = (rounds * cus / tiles_n) * c.bm;
-        }
-        if (m_main > M) m_main = M;
-        cg_launch_cfg<T>(cfg, d, 0, m_main, stream);
-        if (m_main < M) {
+        cg_launch_cfg<T>(pl.cfg, d, 0, pl.m_main, stream);
+        if (pl.m_main < M) {
             AaConvGemm tail = d;
             tail.tile = -1;
-            int tcfg = -1;
-            const int small[2] = {1, 0};
-            for (int k = 0; k < 2 && tcfg < 0; ++k) {
-                const CgCfg& t = kCgCfgs[small[k]];
-                if (d.n_pad % t.bn == 0 && (!d.geglu || (t.bn / t.wn) % 64 == 0)) tcfg = small[k];
-            }
-            if (tcfg < 0) cg_launch_cfg<T>(cfg, d, m_main, M, stream);      // no small tile fits (wide GEGLU): big tile again
-            else cg_launch_cfg<T>(tcfg, tail, m_main, M, stream);
+            cg_launch_cfg<T>(pl.tail_cfg, tail, pl.m_main, M, stream, pl.tail_splits);
+            if (pl.tail_splits > 1) reduce(pl.m_main, pl.tail_splits);
         }
         return finish("conv_gemm");
     }
@@ -263,10 +297,7 @@ size_t aa_conv_gemm_workspace(const AaConvGemm* d) {
     using namespace aa;
     if (!d || !cg_dma_ok(*d)) return 0;
     const int M = (int)((int64_t)d->n_img * d->h_out * d->w_out);
-    const int cfg = cg_choose(*d, M);
-    if (cfg < 0) return 0;
-    const int s = cg_splits(*d, M, kCgCfgs[cfg]);
-    return s > 1 ? (size_t)s * M * d->n_pad * 4 : 0;
+    return cg_plan(*d, M, true).workspace;
 }
 
 int aa_conv_gemm(const AaConvGemm* d, void* stream) {

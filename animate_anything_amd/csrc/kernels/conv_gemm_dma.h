@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const int n_wave = tile_n * BN + wn * (BN / WN);
     if (k_splits > 1) {
         // partial sums straight from the accumulator layout: ws[split][m][n] fp32, 64 contiguous bytes per lane and block
-        float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)blockIdx.y * M * p.n_pad;
+        // (rows are numbered from m_begin: a split-K tail launch keeps partials of its own rows only)
+        float* ws = reinterpret_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * (M - m_begin) - m_begin) * p.n_pad;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m_tile + wm * (BM / WM) + i * 32 + ec;
@@ -465,21 +466,23 @@ namespace aa {
 // Split-K finish: sum the fp32 partials of `splits` K ranges and apply the usual epilogue (bias, row vector,
 // activation, residual, scale); one 16-byte output chunk per thread.
 template <typename T>
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const AaConvGemm p, const int M, const int splits) {
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const AaConvGemm p, const int M, const int m_begin, const int splits) {
     const int cpr = p.n_out >> 3;
-    const int64_t total = (int64_t)M * cpr;
+    const int rows = M - m_begin;                         // the partials cover rows [m_begin, M)
+    const int64_t total = (int64_t)rows * cpr;
     const float* ws = reinterpret_cast<const float*>(p.workspace);
     const T* bias = reinterpret_cast<const T*>(p.bias);
     const T* rowvec = reinterpret_cast<const T*>(p.rowvec);
     const T* resid = reinterpret_cast<const T*>(p.residual);
     T* out = reinterpret_cast<T*>(p.out);
     for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < total; c += (int64_t)gridDim.x * 256) {
-        const int m = (int)(c / cpr), n = (int)(c - (int64_t)m * cpr) * 8;
+        const int ml = (int)(c / cpr), n = (int)(c - (int64_t)ml * cpr) * 8;
+        const int m = m_begin + ml;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.0f;
         for (int sp = 0; sp < splits; ++sp) {
-            const f32x4* src = reinterpret_cast<const f32x4*>(ws + ((int64_t)sp * M + m) * p.n_pad + n);
+            const f32x4* src = reinterpret_cast<const f32x4*>(ws + ((int64_t)sp * rows + ml) * p.n_pad + n);
             const f32x4 a = src[0], b = src[1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }

@@ -361,6 +361,27 @@ def test_sparse_last_round_is_split_to_small_tiles(backend):
     close(y, nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1)).half().float() + res.float())
 
 
+@pytest.mark.parametrize("cfg,N", [(4, 320), (14, 320), (3, 256)])
+def test_sparse_last_round_with_long_k_is_split_along_k(backend, cfg, N):
+    """With a long K loop the leftover tiles of a big-tile launch keep the big tile and are split along K (partials of
+    the tail rows only, reduce over [m_begin, M)) instead of going to small tiles."""
+    from animate_anything_amd import _lib, ops as _ops
+    n, h, w, cin = 3, 15, 16, 384                      # M = 720 rows: 2 full 256-row tiles + 208 left over; K = 3456 = 54 steps
+    x, wt, b = rnd(n, cin, h, w, seed=75), rnd(N, cin, 3, 3, scale=0.04, seed=76), rnd(N, seed=77)
+    g = ops.conv3x3_geom(n, h, w)
+    res, temb = rnd(g.rows, N, seed=78), rnd(n, N, seed=79)
+    lib = _lib.get()
+    lib.aa_set_tile_override(cfg)
+    ops.DEBUG_ABLATE = 4
+    try:
+        y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res, rowvec=temb, rowvec_div=h * w, act=ops.AA_ACT_SILU)
+    finally:
+        lib.aa_set_tile_override(-1)
+        ops.DEBUG_ABLATE = 0
+    ref = nhwc(F.silu(F.conv2d(x.float(), wt.float(), b.float(), padding=1) + temb.float()[:, :, None, None])).half().float() + res.float()
+    close(y, ref)
+
+
 def test_split_k_long_k_few_tiles(backend):
     """Few output tiles + long K: the K loop is split over workgroups (fp32 partials + reduce launch)."""
     M, K, N = 150, 2048, 128
