@@ -150,7 +150,7 @@ static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) 
     const int nk = d.k_pad / c.bk;
     const int tail_tiles = ((M - p.m_main + c.bm - 1) / c.bm) * tiles_n;
     int ts = cus / tail_tiles;                            // workgroups available per leftover tile
-    if (ts > 4) ts = 4;                                   // (each split costs a round trip of fp32 partials)
+    if (ts > 8) ts = 8;                                   // (each split costs a round trip of fp32 partials)
     if (ts > nk / 24) ts = nk / 24;                       // measured: K loops of <= 45 steps are better off with small tiles
     if (have_workspace_or_query && ts >= 2 && !d.geglu) {
         p.tail_cfg = p.cfg;
