@@ -380,6 +380,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     T* out = reinterpret_cast<T*>(p.out);
     const int n_cols = p.geglu ? (p.n_out >> 1) : p.n_out;
     const bool post = resid || p.out_scale != 1.0f;
+    const bool silu = p.act == AA_ACT_SILU;
     const bool pre_is_rv = rowvec != nullptr;             // the prefetch registers carry the row vector, else the residual
 #define AA_ZERO4 (u32x4{0u, 0u, 0u, 0u})          /* a prvalue: `c ? arr[i] : zero_variable` would select between ADDRESSES and pin arr in scratch */
     auto col_of = [&](int j) __attribute__((always_inline)) { return p.geglu ? (n_wave >> 1) + (j >> 1) * 32 + 16 * eh : n_wave + j * 32 + 16 * eh; };
@@ -423,13 +424,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
                 const u32x4 pv = pre[j][q];
                 Pack8<T> r; r.raw = AA_ZERO4;
                 if (pre_is_rv) r.raw = pv;
+                float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = acc[i][j][8 * q + e] + (float)b.e[e] + brow;
-                    if (pre_is_rv) v += (float)r.e[e];
-                    if (p.act == AA_ACT_SILU) v = silu_f(v);
-                    o[q].e[e] = (T)v;
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * q + e] + (float)b.e[e] + brow;
+                if (pre_is_rv) {                          // uniform branches once per eight values, not once per value
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)r.e[e];
                 }
+                if (silu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[q].e[e] = (T)v[e];
             }
         };
         if (p.geglu) {
