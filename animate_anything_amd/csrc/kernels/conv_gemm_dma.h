@@ -494,17 +494,29 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const AaConvGemm p, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
         }
+        // uniform branches once per eight values (not once per value)
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)bias[p.bias_per_row ? m : n + e];
+        }
+        if (rowvec) {
+            const T* rv = rowvec + (int64_t)(m / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out) + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        }
+        if (p.act == AA_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)(T)v[e];            // same rounding point as the fused epilogue
+        if (resid) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)resid[(int64_t)m * p.ldr + n + e];
+        }
         Pack8<T> o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = v[e];
-            if (bias) x += (float)bias[p.bias_per_row ? m : n + e];
-            if (rowvec) x += (float)rowvec[(int64_t)(m / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out) + n + e];
-            if (p.act == AA_ACT_SILU) x = silu_f(x);
-            x = (float)(T)x;                                       // same rounding point as the fused epilogue
-            if (resid) x += (float)resid[(int64_t)m * p.ldr + n + e];
-            o.e[e] = (T)(x * p.out_scale);
-        }
+        for (int e = 0; e < 8; ++e) o.e[e] = (T)(v[e] * p.out_scale);
         *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + n) = o.raw;
     }
 }

@@ -162,14 +162,18 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_apply_kernel(const AaGro
         float sc[8], sh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sc[e] = s_scale[slot * 8 + e]; sh[e] = s_shift[slot * 8 + e]; }
+        const bool silu = p.silu != 0;
         auto norm8 = [&](Pack8<T> v) {
             Pack8<T> o;
+            float f[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = (float)v.e[e] * sc[e] + sh[e];
-                if (p.silu) f = f / (1.0f + __expf(-f));
-                o.e[e] = (T)f;
+            for (int e = 0; e < 8; ++e) f[e] = (float)v.e[e] * sc[e] + sh[e];
+            if (silu) {                                   // one uniform branch per eight values, not one per value
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] / (1.0f + __expf(-f[e]));
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = (T)f[e];
             return o;
         };
         int t = t_begin + roff;
