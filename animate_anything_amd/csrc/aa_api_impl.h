@@ -67,7 +67,7 @@ static const CgCfg kCgCfgs[] = {
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
-static int g_tile_override = -2;   // -2: read AA_FORCE_CFG once; -1: automatic; >= 0: forced index
+static thread_local int g_tile_override = -2;   // per calling thread.  -2: read AA_FORCE_CFG once; -1: automatic; >= 0: forced index
 static int cg_force_cfg() {
     if (g_tile_override == -2) { const char* e = getenv("AA_FORCE_CFG"); g_tile_override = e ? atoi(e) : -1; }
     return g_tile_override;

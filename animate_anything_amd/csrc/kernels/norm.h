@@ -27,6 +27,13 @@ __device__ __forceinline__ u32x4 load8(const T* x0, const T* x1, int c0, int c1,
     const T* src = (c < c0) ? x0 + token * c0 + c : x1 + token * c1 + (c - c0);
     return *reinterpret_cast<const u32x4*>(src);
 }
+// GroupNorm statistics are accumulated on values CENTRED on a per-(image group, channel group) pivot - the group's first
+// element (first token, first channel) - so that var = E[(x-K)^2] - E[x-K]^2 does not cancel when |mean| >> std
+// (activations of trained checkpoints are not zero-mean; torch's own kernel uses Welford for the same reason).
+template <typename T>
+__device__ __forceinline__ float gn_pivot(const T* x0, const T* x1, int c0, int c1, int64_t first_token, int c) {
+    return (float)((c < c0) ? x0[first_token * c0 + c] : x1[first_token * c1 + (c - c0)]);
+}
 
 // ---- GroupNorm pass 1: per (image group, chunk) partial sums of x and x^2 for every channel group.
 // grid = (chunks, n_groups_img).  partial layout: [img_group][chunk][group][2] fp32.
@@ -54,10 +61,13 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_stats_kernel(const AaGro
         const int slot = s0 + (S <= GN_THREADS ? lin % S : lin);
         const int roff = S <= GN_THREADS ? lin / S : 0;
         const bool active = slot < S && roff < rows_per_pass;
-        float a[8], b[8];
+        float a[8], b[8], kp[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a[e] = 0.0f; b[e] = 0.0f; }
+        for (int e = 0; e < 8; ++e) { a[e] = 0.0f; b[e] = 0.0f; kp[e] = 0.0f; }
         if (active) {
+            const int cg = C / p.num_groups;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kp[e] = gn_pivot<T>(x0, x1, p.c0, p.c1, base, ((slot * 8 + e) / cg) * cg);
             int t = t_begin + roff;
             for (; t + rows_per_pass < t_end; t += 2 * rows_per_pass) {      // two independent rows in flight
                 Pack8<T> v, w;
@@ -65,14 +75,14 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_stats_kernel(const AaGro
                 w.raw = load8<T>(x0, x1, p.c0, p.c1, base + t + rows_per_pass, slot * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v.e[e], g = (float)w.e[e];
+                    const float f = (float)v.e[e] - kp[e], g = (float)w.e[e] - kp[e];
                     a[e] += f + g; b[e] += f * f + g * g;
                 }
             }
             if (t < t_end) {
                 Pack8<T> v; v.raw = load8<T>(x0, x1, p.c0, p.c1, base + t, slot * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = (float)v.e[e]; a[e] += f; b[e] += f * f; }
+                for (int e = 0; e < 8; ++e) { const float f = (float)v.e[e] - kp[e]; a[e] += f; b[e] += f * f; }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -125,8 +135,10 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_apply_kernel(const AaGro
             float sa = 0.0f, sb = 0.0f;
             for (int jj = 0; jj < lanes; ++jj) { sa += s_red[(jj * G + tid) * 2]; sb += s_red[(jj * G + tid) * 2 + 1]; }
             const float cnt = (float)p.tokens_per_group * (float)(C / G);
-            const float mean = sa / cnt;
-            const float var = fmaxf(sb / cnt - mean * mean, 0.0f);
+            const float dm = sa / cnt;                                       // mean of the pivot-centred values
+            const float var = fmaxf(sb / cnt - dm * dm, 0.0f);
+            const float mean = dm + gn_pivot<T>(reinterpret_cast<const T*>(p.x0), reinterpret_cast<const T*>(p.x1), p.c0, p.c1,
+                                                (int64_t)ig * p.tokens_per_group, tid * (C / G));
             s_red[(lanes * G + tid) * 2] = mean;
             s_red[(lanes * G + tid) * 2 + 1] = rsqrtf(var + p.eps);
         }

@@ -25,7 +25,11 @@ def init(backend: str | None = None):
     if cuda:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend or ("nccl" if cuda else "gloo"))
+        backend = backend or ("nccl" if cuda else "gloo")
+        if backend == "nccl" and cuda:
+            dist.init_process_group(backend, device_id=device)      # binds the RCCL communicator to this rank's GPU
+        else:
+            dist.init_process_group(backend)
     return rank, world, device
 
 

@@ -90,7 +90,10 @@ def save_gif(path, frames, fps):
 
 
 # ----------------------------------------------------------------------------- model loading (train.py:85-104)
-def load_primary_models(pretrained_model_path, motion_mask=True, motion_strength=True):
+def load_primary_models(pretrained_model_path, motion_mask=None, motion_strength=None):
+    """reference train.py:85-104.  As there, `unet/config.json` of the checkpoint decides whether the mask input conv
+    (`conv_in2`) and the motion-strength embedding are active (`from_pretrained(subfolder="unet")` without overrides,
+    train.py:89); `motion_mask` / `motion_strength` override the checkpoint only when given (not None)."""
     sched_cfg = os.path.join(pretrained_model_path, "scheduler", "scheduler_config.json")
     scfg = json.load(open(sched_cfg)) if os.path.exists(sched_cfg) else {}
     noise_scheduler = DDPMScheduler(**{k: v for k, v in scfg.items() if not k.startswith("_")})
@@ -102,8 +105,8 @@ def load_primary_models(pretrained_model_path, motion_mask=True, motion_strength
     except Exception:
         pass
     vae = AutoencoderKL.from_pretrained(pretrained_model_path, subfolder="vae")
-    unet = UNet3DConditionModel.from_pretrained(pretrained_model_path, subfolder="unet",
-                                                motion_mask=motion_mask, motion_strength=motion_strength)
+    overrides = {k: v for k, v in (("motion_mask", motion_mask), ("motion_strength", motion_strength)) if v is not None}
+    unet = UNet3DConditionModel.from_pretrained(pretrained_model_path, subfolder="unet", **overrides)
     return noise_scheduler, tokenizer, text_encoder, vae, unet, scfg
 
 
@@ -156,15 +159,20 @@ def eval(pipeline, validation_data, out_file, index, forward_t=25, preview=True,
 
 
 def batch_eval(unet, text_encoder, vae, tokenizer, scheduler_config, validation_data, output_dir, preview,
-               global_step=0, iters=6, generator=None):
-    """train.py:793-823: pipeline with DPM-Solver++ built from the checkpoint's scheduler config, `iters` samples."""
+               global_step=0, iters=6, generator=None, indices=None, seed=None):
+    """train.py:793-823: pipeline with DPM-Solver++ built from the checkpoint's scheduler config, `iters` samples.
+    `indices` (clip sharding, main_eval): render only these sample indices, each with its own generator seeded
+    `seed + index` (distributed.clip_seed) so that a sample does not depend on which rank renders it."""
     unet.eval()
     scheduler = DPMSolverMultistepScheduler.from_config(scheduler_config)
     pipeline = LatentToVideoPipeline(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, unet=unet,
                                      scheduler=scheduler)
     scheduler.set_timesteps(validation_data.num_inference_steps, device=vae.device)
     results = []
-    for t in range(iters):
+    from .distributed import clip_seed
+    for t in (range(iters) if indices is None else indices):
+        if indices is not None and seed is not None:
+            generator = torch.Generator(device=vae.device).manual_seed(clip_seed(seed, t))
         name = os.path.basename(validation_data.prompt_image)
         out_dir = f"{output_dir}/{name.split('.')[0]}"
         os.makedirs(out_dir, exist_ok=True)
@@ -174,9 +182,17 @@ def batch_eval(unet, text_encoder, vae, tokenizer, scheduler_config, validation_
     return results
 
 
-def main_eval(pretrained_model_path, validation_data, seed=None, motion_mask=False, motion_strength=False,
+def main_eval(pretrained_model_path, validation_data, seed=None, motion_mask=None, motion_strength=None,
               output_dir="output/demo", iters=6, dtype="fp16", graph=True, **kwargs):
-    """train.py:825-857.  Weights are cast to half precision on the GPU ("cuda" is the HIP device on ROCm)."""
+    """train.py:825-857.  Weights are cast to half precision on the GPU ("cuda" is the HIP device on ROCm).
+    The reference accepts `motion_mask` / `motion_strength` here and never forwards them to the UNet constructor
+    (train.py:838: the checkpoint's config.json governs); so do we - they are passed on only when the YAML sets them.
+
+    Under `torchrun` (WORLD_SIZE > 1: BASELINE.json configs[2], "bs=8, 1 clip/GPU") the `iters` samples of the clip batch
+    are sharded round-robin over the ranks (rank r renders samples r, r+W, ...; per-sample seed = seed + index so the
+    outputs do not depend on W) and the final latents are all-gathered over RCCL (distributed.gather_clips)."""
+    from . import distributed as D
+    rank, world, _dev = D.init()
     generator = None
     if seed is not None:
         torch.manual_seed(seed)
@@ -190,8 +206,23 @@ def main_eval(pretrained_model_path, validation_data, seed=None, motion_mask=Fal
             m.to(torch.device("cuda"), dtype=weight_dtype)
     if graph:
         unet.enable_graph()
-    return batch_eval(unet, text_encoder, vae, tokenizer, scfg, validation_data, output_dir, True, iters=iters,
-                      generator=generator)
+    if world == 1:
+        return batch_eval(unet, text_encoder, vae, tokenizer, scfg, validation_data, output_dir, True, iters=iters,
+                          generator=generator)
+    mine = D.clip_indices(iters, rank, world)
+    results = batch_eval(unet, text_encoder, vae, tokenizer, scfg, validation_data, output_dir, True, iters=iters,
+                         generator=generator, indices=mine, seed=seed)
+    local = torch.stack([r[2][0] for r in results]) if results else None
+    shape = [0] * 5
+    if local is not None:
+        shape = list(local.shape)
+    import torch.distributed as dist
+    t = torch.tensor(shape, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # ranks without a clip learn the per-clip shape
+    if local is None:
+        local = torch.zeros([0] + t.tolist()[1:], dtype=weight_dtype, device="cuda")
+    gathered = D.gather_clips(local.contiguous(), iters, rank, world)        # [iters, 4, frames, h, w] on every rank
+    return results, gathered
 
 
 def main(argv=None):

@@ -44,9 +44,16 @@ class Grid:
         return replace(self, h=h, w=w)
 
 
+def weights_key(*tensors):
+    """Identity + in-place version of the source parameters of a packed-weight cache: a cache built from other storage, or
+    from the same storage before an in-place update (load_state_dict copies in place, LoRA merges, optimiser steps), is stale."""
+    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+
+
 class _Packed:
-    """Mixin: caches the kernel-side weight layout; dropped whenever the module is moved/cast."""
+    """Mixin: caches the kernel-side weight layout, keyed on the parameters' storage and in-place version."""
     _pw = None
+    _pw_key = None
 
     def _apply(self, fn, *a, **k):
         self._pw = None
@@ -56,17 +63,18 @@ class _Packed:
         self._pw = None
         return super()._load_from_state_dict(*a, **k)
 
+    def packed(self):
+        key = weights_key(self.weight, self.bias)
+        if self._pw is None or self._pw_key != key:
+            self._pw, self._pw_key = ops.pack_weight(self.weight, self.bias), key
+        return self._pw
+
 
 def _no_eager(name):
     raise RuntimeError(f"{name}: this module only runs through the HIP token path of animate_anything_amd")
 
 
 class Linear(_Packed, nn.Linear):
-    def packed(self):
-        if self._pw is None:
-            self._pw = ops.pack_weight(self.weight, self.bias)
-        return self._pw
-
     def tokens(self, x, **epilogue):
         return ops.conv_gemm(x, self.packed(), ops.linear_geom(x.shape[0]), **epilogue)
 
@@ -75,11 +83,6 @@ class Linear(_Packed, nn.Linear):
 
 
 class Conv2d(_Packed, nn.Conv2d):
-    def packed(self):
-        if self._pw is None:
-            self._pw = ops.pack_weight(self.weight, self.bias)
-        return self._pw
-
     def tokens(self, x, geom, **epilogue):
         return ops.conv_gemm(x, self.packed(), geom, **epilogue)
 
@@ -88,11 +91,6 @@ class Conv2d(_Packed, nn.Conv2d):
 
 
 class Conv3d(_Packed, nn.Conv3d):
-    def packed(self):
-        if self._pw is None:
-            self._pw = ops.pack_weight(self.weight, self.bias)
-        return self._pw
-
     def tokens(self, x, geom, **epilogue):
         return ops.conv_gemm(x, self.packed(), geom, **epilogue)
 
@@ -242,6 +240,7 @@ class Attention(nn.Module):
         self.to_v = Linear(kv_dim, inner, bias=False)
         self.to_out = nn.ModuleList([Linear(inner, query_dim), nn.Dropout(0.0)])
         self._fused = None
+        self._fused_key = None
         self.kv = None
 
     def _apply(self, fn, *a, **k):
@@ -249,10 +248,11 @@ class Attention(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def fused(self):
-        if self._fused is None:
-            rows = [self.to_k.weight, self.to_v.weight] if self.is_cross else \
-                   [self.to_q.weight, self.to_k.weight, self.to_v.weight]
-            self._fused = ops.pack_weight(torch.cat([r.detach() for r in rows], dim=0))
+        rows = [self.to_k.weight, self.to_v.weight] if self.is_cross else \
+               [self.to_q.weight, self.to_k.weight, self.to_v.weight]
+        key = weights_key(*rows)
+        if self._fused is None or self._fused_key != key:
+            self._fused, self._fused_key = ops.pack_weight(torch.cat([r.detach() for r in rows], dim=0)), key
         return self._fused
 
     def text_kv(self, text_tokens):
@@ -286,15 +286,20 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = Linear(dim_in, dim_out * 2)
         self._pw = None
+        self._pw_key = None
 
     def _apply(self, fn, *a, **k):
         self._pw = None
         return super()._apply(fn, *a, **k)
 
+    def packed(self):
+        key = weights_key(self.proj.weight, self.proj.bias)
+        if self._pw is None or self._pw_key != key:
+            self._pw, self._pw_key = ops.pack_weight(self.proj.weight, self.proj.bias, geglu=True), key
+        return self._pw
+
     def tokens(self, x):
-        if self._pw is None:
-            self._pw = ops.pack_weight(self.proj.weight, self.proj.bias, geglu=True)
-        return ops.conv_gemm(x, self._pw, ops.linear_geom(x.shape[0]))
+        return ops.conv_gemm(x, self.packed(), ops.linear_geom(x.shape[0]))
 
 
 class FeedForward(nn.Module):

@@ -234,16 +234,33 @@ class UNet3DConditionModel(nn.Module):
         return next(self.parameters()).device
 
     def _apply(self, fn, *a, **k):
-        self._graph = None
+        self.invalidate_caches()
+        return super()._apply(fn, *a, **k)
+
+    def invalidate_caches(self):
+        """Drop every derived copy of the weights: the batched time-embedding / text K|V packs and the captured hipGraphs
+        (which replay launches that point at the packed copies).  Called on `.to()` / `load_state_dict()`; call it by hand
+        after editing parameters in place while a graph is enabled (the per-layer packs notice in-place edits themselves,
+        a captured graph cannot)."""
         self._temb_pack = None
         self._text_pack = None
-        return super()._apply(fn, *a, **k)
+        if getattr(self, "_graph", None) is not None:
+            self._graph = {}
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.invalidate_caches()
+        return out
 
     def _project_text(self, text_tokens):
         """K | V of the text for every cross-attention layer as ONE contraction; each layer receives its column slice."""
-        from .layers import Attention
-        if getattr(self, "_text_pack", None) is None:
-            layers_ = [m for m in self.modules() if isinstance(m, Attention) and m.is_cross]
+        from .layers import Attention, weights_key
+        if getattr(self, "_text_layers", None) is None:
+            self._text_layers = [m for m in self.modules() if isinstance(m, Attention) and m.is_cross]
+        key = weights_key(*[w_ for a in self._text_layers for w_ in (a.to_k.weight, a.to_v.weight)])
+        if getattr(self, "_text_pack", None) is None or self._text_key != key:
+            self._text_key = key
+            layers_ = self._text_layers
             w = torch.cat([torch.cat([a.to_k.weight.detach(), a.to_v.weight.detach()], dim=0) for a in layers_], dim=0)
             offs, o = [], 0
             for a in layers_:
@@ -258,9 +275,13 @@ class UNet3DConditionModel(nn.Module):
     def _project_time_embeddings(self, temb_silu):
         """All ResnetBlock2D.time_emb_proj of the network as ONE contraction (31 two-row GEMMs otherwise, each a
         latency-bound launch): rows of the weights concatenated, every block receives its column slice."""
-        from .layers import ResnetBlock2D
-        if getattr(self, "_temb_pack", None) is None:
-            blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
+        from .layers import ResnetBlock2D, weights_key
+        if getattr(self, "_temb_blocks", None) is None:
+            self._temb_blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
+        key = weights_key(*[w_ for b in self._temb_blocks for w_ in (b.time_emb_proj.weight, b.time_emb_proj.bias)])
+        if getattr(self, "_temb_pack", None) is None or self._temb_key != key:
+            self._temb_key = key
+            blocks = self._temb_blocks
             w = torch.cat([b.time_emb_proj.weight.detach() for b in blocks], dim=0)
             bias = torch.cat([b.time_emb_proj.bias.detach() for b in blocks], dim=0)
             offs, o = [], 0

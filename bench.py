@@ -8,9 +8,15 @@ v1.02 architecture (1413 M parameters) and synthetic latents/text (SURVEY.md sec
 resident in HBM before the timed region.  With N GPUs every rank denoises its own clip (weak scaling,
 no data-path collective) and the final latents are all-gathered over RCCL once at the end.
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); under torchrun `--gpus` must equal
+WORLD_SIZE.  Clip ownership / seeds / the final gather are animate_anything_amd.distributed.
+
 Prints ONE JSON line (rank 0).  `roofline` re-times the dominant kernel (the implicit-GEMM
-contraction, conv_gemm_kernel) in isolation with events on its own stream; `cpu_baseline` times the
-CPU oracle (oracle/, a restatement of the reference: "port") on a bounded sample of the same workload.
+contraction, aa::conv_gemm_dma_kernel) in isolation with events on its own stream; `cpu_baseline` times the
+CPU oracle (oracle/, a restatement of the reference: "port") on BASELINE.json configs[0] (8 frames x 256x256, the
+reference's own CPU-runnable case) - a full forward, median of 3 - and quotes the one full 16x512x512 forward measured
+offline on the same class of host (profiles/r02_cpu_baseline.json).
 """
 import argparse
 import json
@@ -38,6 +44,7 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-tile-cache", action="store_true", help="ignore the committed tile choices (animate_anything_amd/tile_cache_gfx950.json): autotune everything")
     p.add_argument("--tile-cache", default="", help="json file with autotuned tile choices: loaded if present, written after warm-up")
     p.add_argument("--gemm-breakdown", default="", help="write a per-shape table of the contraction launches of one step")
     return p.parse_args()
@@ -67,40 +74,82 @@ def synthetic_inputs(frames, lat, dtype, device, seed=1234):
     return {k: v.to(device=device, dtype=dtype if k != "latents" else torch.float32) for k, v in d.items()}
 
 
-def cpu_baseline(frames_sample, lat_full, lat=32):
-    """Oracle UNet forward (fp32 CPU, `cores` threads) on a bounded sample of the workload: the CFG batch
-    of 2, `frames_sample`+1 of the 17 frames, at `lat`x`lat` instead of 64x64 latents; steps/s scaled by
-    the token ratio (all per-token costs are linear except spatial attention, which this under-counts)."""
+def cpu_baseline(reps=3):
+    """The oracle (CPU restatement of the reference: kind "port") on the host cores, a REAL measurement of a whole
+    workload, no extrapolation: BASELINE.json configs[0] - 8 frames x 256x256 (latents [2,4,8,32,32] with CFG, 9 frames
+    inside; 5.495 TFLOP per step) - one full UNet3D forward, median of `reps`.  `value` is that
+    configuration's steps/s.  The one full 16 frames x 512x512 forward (44.262 TFLOP) measured offline on the GPU box's
+    host cores is quoted from profiles/r02_cpu_baseline.json when present (`full_config_*`)."""
     import oracle
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    net = oracle.UNet3DConditionModel(motion_mask=True, motion_strength=True).eval()
+    # timing does not depend on the weight values: skip the 1.4 G-element default init, fill with small uniforms
+    with torch.device("meta"):
+        net = oracle.UNet3DConditionModel(motion_mask=True, motion_strength=True)
+    net = net.to_empty(device="cpu").eval()
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if p_.dim() == 1 and "norm" in n_ and n_.endswith("weight"):
+                p_.fill_(1.0)
+            else:
+                p_.uniform_(-0.03, 0.03, generator=g)
     g = torch.Generator().manual_seed(1234)
     r = lambda *s: torch.randn(*s, generator=g)
-    x, c, txt = r(2, 4, frames_sample, lat, lat), r(2, 4, 1, lat, lat), r(2, 77, 1024)
+    lat, frames = 32, 8
+    x, c, txt = r(2, 4, frames, lat, lat), r(2, 4, 1, lat, lat), r(2, 77, 1024)
     m = torch.zeros(1, 1, 1, lat, lat)
-    t0 = time.perf_counter()
+    m[..., 8:24, 8:24] = 1
+    ts = []
     with torch.no_grad():
-        net(x, 500, txt, c, m, motion=torch.tensor([3.0]))
-    dt = time.perf_counter() - t0
-    scale = 17.0 / (frames_sample + 1) * (lat_full / lat) ** 2
-    return dict(value=1.0 / (dt * scale), unit="steps/s", cores=cores, kind="port",
-                sample=f"oracle UNet3D forward fp32 on {cores} threads, CFG batch 2, {frames_sample}+1 of 16+1 frames at "
-                       f"{lat}x{lat} (of {lat_full}x{lat_full}) latents, {dt:.1f} s measured, scaled x{scale:.1f} by token count")
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            y = net(x, 500, txt, c, m, motion=torch.tensor([3.0])).sample
+            ts.append(time.perf_counter() - t0)
+    assert torch.isfinite(y).all()
+    ts.sort()
+    dt = ts[len(ts) // 2]
+    out = dict(value=round(1.0 / dt, 5), unit="steps/s", cores=cores, kind="port",
+               sample=f"oracle UNet3D forward fp32 on {cores} threads, BASELINE configs[0]: 8 frames x 256x256 (latents "
+                      f"[2,4,8,32,32] with CFG, 9 frames inside, 5.495 TFLOP), whole forward, median of {reps}: {dt:.2f} s "
+                      f"(all runs {', '.join('%.2f' % t for t in ts)} s); value = steps/s OF THAT CONFIG, not of the 16fx512x512 metric",
+               tflops=round(5.495 / dt, 3))
+    full = os.path.join(ROOT, "profiles", "r02_cpu_baseline.json")
+    if os.path.exists(full):
+        rec = json.load(open(full))
+        out["full_config_steps_per_s"] = rec.get("steps_per_s")
+        out["full_config_note"] = (f"one full 16fx512x512 CFG forward (44.262 TFLOP) measured offline: {rec.get('seconds_per_step'):.1f} s "
+                                   f"on {rec.get('cores')} threads of {rec.get('cpu')} (profiles/r02_cpu_baseline.json)")
+    return out
+
+
+def respawn_under_torchrun(a):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start N ranks on this node, one per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        respawn_under_torchrun(a)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    from animate_anything_amd import distributed as D
+    rank, world, device = D.init("nccl")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        n_ranks = torch.ones(1, device=device)
+        dist.all_reduce(n_ranks)                              # RCCL sanity: every rank is really there
+        assert int(n_ranks.item()) == world
     dtype = torch.float16 if a.dtype == "fp16" else torch.bfloat16
 
     from animate_anything_amd import ops
@@ -110,13 +159,17 @@ def main():
     lat = a.size // 8
     unet = build_unet(dtype, device)
     pipe = LatentToVideoPipeline(vae=None, unet=unet, scheduler=DPMSolverMultistepScheduler())
-    inp = synthetic_inputs(a.frames, lat, dtype, device, seed=1234 + rank)      # one clip per rank
+    num_clips = world                                                             # weak scaling: one clip per GPU
+    mine = D.clip_indices(num_clips, rank, world)                                 # == [rank]
+    inp = synthetic_inputs(a.frames, lat, dtype, device, seed=D.clip_seed(1234, mine[0]))
     embeds = torch.cat([inp["neg"], inp["text"]])
     total = a.warmup + a.steps
     pipe.scheduler.set_timesteps(max(total, 2))
     ts = [int(t) for t in pipe.scheduler.timesteps][:total]
     if not a.no_graph:
         unet.enable_graph()
+    if a.no_tile_cache:
+        os.environ["AA_NO_TILE_CACHE"] = "1"
     if a.tile_cache and os.path.exists(a.tile_cache):
         ops.load_tile_cache(a.tile_cache)
 
@@ -135,16 +188,17 @@ def main():
         barrier()
         t0 = time.perf_counter()
         x = run(ts[a.warmup:], x)
-        if world > 1:
-            gathered = torch.empty((world,) + tuple(x.shape[1:]), dtype=dtype, device=device)
-            dist.all_gather_into_tensor(gathered, x.to(dtype).contiguous())
+        gathered = D.gather_clips(x.to(dtype).contiguous(), num_clips, rank, world)   # the ONE collective (RCCL all-gather)
         barrier()
         dt = time.perf_counter() - t0
+    per_rank_ms = [dt / a.steps * 1e3]
     if world > 1:
-        tmax = torch.tensor([dt], device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
-    assert torch.isfinite(x).all(), "non-finite latents"
+        tall = [torch.zeros(1, device=device) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([dt], device=device))
+        per_rank_ms = [round(t.item() / a.steps * 1e3, 3) for t in tall]
+        dt = max(t.item() for t in tall)
+    assert gathered.shape[0] == num_clips
+    assert torch.isfinite(x).all() and torch.isfinite(gathered).all(), "non-finite latents"
 
     ms_step = dt / a.steps * 1e3
     value = world * a.steps / dt
@@ -155,7 +209,9 @@ def main():
         "config": {"workload": f"animate_anything_512_v1.02 UNet3D (1413M params, seeded random init), "
                                f"{a.frames} frames x {a.size}x{a.size}, pipeline bs=1 per GPU (CFG batch 2, 17 frames "
                                f"inside), DPM-Solver++ step, hipGraph={'off' if a.no_graph else 'on'}",
-                   "clips_per_gpu": 1, "parallelism": f"clip-sharded x{world}"},
+                   "clips_per_gpu": 1, "clips": num_clips, "parallelism": f"clip-sharded x{world}",
+                   "collective": "none in the data path; one all_gather_into_tensor of the final latents (RCCL)" if world > 1 else "none"},
+        "per_rank_ms_per_step": per_rank_ms,
         "tflops_per_gpu": round(FLOP_PER_STEP * (a.steps / dt) / 1e12 * (a.frames + 1) / 17 * (lat / 64) ** 2, 2),
     }
 
@@ -212,18 +268,21 @@ def main():
         # HBM bytes per launch of the dominant kernel: PMC numbers (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # separate rocprofv3 passes, scripts/pmc_traffic.sh) committed under profiles/ - bench.py cannot run the
         # profiler on itself, so `traffic` is the last committed measurement of the same command (null if absent)
-        traffic, tpath = None, os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("conv_gemm_dma_kernel", {}).get("hbm_bytes_per_launch")
+        traffic, tname = None, None
+        for tname_ in ("r02_traffic_pmc.json", "r01_traffic_pmc.json"):
+            tpath = os.path.join(ROOT, "profiles", tname_)
+            if os.path.exists(tpath):
+                traffic, tname = json.load(open(tpath)).get("conv_gemm_dma_kernel", {}).get("hbm_bytes_per_launch"), tname_
+                break
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                           "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_traffic_pmc.json)",
-                           "kernel": "aa::conv_gemm_kernel (implicit-GEMM conv/linear, all instances)",
+                           "traffic_unit": f"HBM bytes per launch (PMC, profiles/{tname})",
+                           "kernel": "aa::conv_gemm_dma_kernel (LDS-DMA implicit-GEMM conv/linear, all instances)",
                            "launches_per_step": len(trace), "avg_launch_us": round(gemm_ms * 1e3 / len(trace), 2),
                            "flop_per_step_in_kernel": flops, "kernel_ms_per_step": round(gemm_ms, 3),
                            "whole_step_frac_of_peak": round(FLOP_PER_STEP * (a.steps / dt) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(1, lat)
+        out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

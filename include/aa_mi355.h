@@ -105,7 +105,8 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream);
 int aa_conv_gemm_tile_info(int idx, int32_t info[7]);
 
 /* Tuning / test aid: force tile shape `cfg` (index into the table in csrc/aa_api_impl.h) for every
- * following aa_conv_gemm call whose packed width it divides; cfg < 0 restores the automatic choice. */
+ * following aa_conv_gemm call OF THE CALLING THREAD whose packed width it divides; cfg < 0 restores the automatic
+ * choice (thread-local, like aa_last_error: the library keeps no process-global mutable state). */
 void aa_set_tile_override(int cfg);
 
 /* ----------------------------------------------------------------------------------------------

@@ -14,7 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <functional>
+#include <memory>
+#include <thread>
 #include <vector>
 #include "types.h"
 
@@ -32,10 +35,11 @@ struct dim3 {
 namespace emu {
 struct Fiber {
     ucontext_t ctx;
-    std::vector<char> stack;
+    std::unique_ptr<char[]> stack;      // allocated once per worker thread and launch, reused block after block
     bool done = false;
     dim3 tid;
 };
+constexpr size_t kStackBytes = 256 * 1024;
 struct Block {
     std::vector<Fiber> fibers;
     ucontext_t sched;
@@ -49,10 +53,13 @@ struct Block {
     std::vector<char> lds;
     std::function<void()> body;
 };
-inline Block*& blk() { static Block* b = nullptr; return b; }
+inline Block*& blk() { static thread_local Block* b = nullptr; return b; }
 }  // namespace emu
 
-inline dim3 threadIdx, blockIdx, blockDim, gridDim;
+// workgroups are independent: a launch spreads them over OS threads (AA_EMU_THREADS, default = hardware threads); the
+// per-workgroup state (current block, the running fiber's indices) is thread-local
+inline thread_local dim3 threadIdx, blockIdx;
+inline dim3 blockDim, gridDim;
 
 namespace emu {
 inline void yield() {
@@ -95,41 +102,60 @@ inline void fiber_entry() {
     swapcontext(&b->fibers[b->cur].ctx, &b->sched);
 }
 // Run `body` once per thread of a grid x block launch with `lds_bytes` of dynamic LDS per block.
+inline void run_blocks(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body, std::atomic<long>& next) {
+    const int nthreads = block.x * block.y * block.z;
+    const long total = (long)grid.x * grid.y * grid.z;
+    const int nw = (nthreads + 63) / 64;
+    Block b;
+    b.body = body;
+    b.fibers.resize(nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        b.fibers[t].stack.reset(new char[kStackBytes]);
+        b.fibers[t].tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+    }
+    blk() = &b;
+    for (long idx = next.fetch_add(1); idx < total; idx = next.fetch_add(1)) {
+        b.lds.assign(lds_bytes + 64, (char)0xAB);
+        b.wave_count.assign(nw, 0); b.wave_gen.assign(nw, 0);
+        b.wave_slots.assign(nw, std::vector<const void*>(64, nullptr));
+        b.alive = nthreads; b.bar_count = 0; b.bar_gen = 0; b.cur = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            Fiber& f = b.fibers[t];
+            f.done = false;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack.get();
+            f.ctx.uc_stack.ss_size = kStackBytes;
+            f.ctx.uc_link = nullptr;
+            makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        }
+        blockIdx = dim3((unsigned)(idx % grid.x), (unsigned)((idx / grid.x) % grid.y), (unsigned)(idx / ((long)grid.x * grid.y)));
+        while (b.alive > 0)
+            for (int t = 0; t < nthreads; ++t) {
+                if (b.fibers[t].done) continue;
+                b.cur = t;
+                threadIdx = b.fibers[t].tid;
+                swapcontext(&b.sched, &b.fibers[t].ctx);
+            }
+    }
+    blk() = nullptr;
+}
+inline int worker_count() {
+    static const int n = [] {
+        const char* e = getenv("AA_EMU_THREADS");
+        int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    return n;
+}
 inline void launch(dim3 grid, dim3 block, size_t lds_bytes, std::function<void()> body) {
     gridDim = grid; blockDim = block;
-    const int nthreads = block.x * block.y * block.z;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
-                Block b;
-                blk() = &b;
-                b.body = body;
-                b.lds.assign(lds_bytes + 64, (char)0xAB);
-                b.fibers.resize(nthreads);
-                const int nw = (nthreads + 63) / 64;
-                b.wave_count.assign(nw, 0); b.wave_gen.assign(nw, 0);
-                b.wave_slots.assign(nw, std::vector<const void*>(64, nullptr));
-                b.alive = nthreads;
-                for (int t = 0; t < nthreads; ++t) {
-                    Fiber& f = b.fibers[t];
-                    f.stack.resize(256 * 1024);
-                    f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = f.stack.data();
-                    f.ctx.uc_stack.ss_size = f.stack.size();
-                    f.ctx.uc_link = nullptr;
-                    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
-                }
-                blockIdx = dim3(bx, by, bz);
-                while (b.alive > 0)
-                    for (int t = 0; t < nthreads; ++t) {
-                        if (b.fibers[t].done) continue;
-                        b.cur = t;
-                        threadIdx = b.fibers[t].tid;
-                        swapcontext(&b.sched, &b.fibers[t].ctx);
-                    }
-                blk() = nullptr;
-            }
+    const long total = (long)grid.x * grid.y * grid.z;
+    std::atomic<long> next{0};
+    const int workers = (int)std::min<long>(worker_count(), total);
+    if (workers <= 1) { run_blocks(grid, block, lds_bytes, body, next); return; }
+    std::vector<std::thread> pool;
+    for (int w = 0; w < workers; ++w) pool.emplace_back([&] { run_blocks(grid, block, lds_bytes, body, next); });
+    for (auto& t : pool) t.join();
 }
 }  // namespace emu
 
@@ -195,7 +221,7 @@ inline f32x16 mfma_32x32x16(f16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma
 inline f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<bf16_t>(a, b, c); }
 
 inline void idle_a_while() {}
-inline long long clock_now() { static long long t = 0; return t += 64; }
+inline long long clock_now() { static thread_local long long t = 0; return t += 64; }
 inline const void* zero_page() { static const u32x4 z[4] = {}; return z; }
 inline void async_copy16(const void* gsrc, void* lds_wave_base) {
     std::memcpy(static_cast<char*>(lds_wave_base) + (emu::linear_tid() & 63) * 16, gsrc, 16);

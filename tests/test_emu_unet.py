@@ -25,3 +25,42 @@ def test_tiny_unet_matches_oracle(emu, h, w):
                   motion=i["motion"]).sample
     assert got.shape == want.shape == (2, 4, 2, h, w)
     assert rel_err(got, want) < 3e-2
+
+
+def test_weight_caches_follow_load_state_dict_and_in_place_updates(emu):
+    """the fused copies of the weights (Q|K|V, GEGLU, the batched time-embedding / text K|V packs) must be
+    rebuilt after load_state_dict() and after in-place parameter edits - forward, load new weights, forward, compare
+    with the oracle carrying the same new weights."""
+    torch.manual_seed(0)
+    ref = oracle.UNet3DConditionModel(**TINY_UNET).eval()
+    net = UNet3DConditionModel(**TINY_UNET).eval().half()
+    i = unet_inputs(h=5, w=6, text_len=9)
+
+    def both(state):
+        ref.load_state_dict(state)
+        net.load_state_dict(state)                     # copies into the existing fp16 parameters in place
+        with torch.no_grad():
+            want = ref(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
+            got = net(i["sample"].half(), i["t"], i["text"].half(), i["cond"].half(), i["mask"].half(),
+                      motion=i["motion"]).sample
+        return rel_err(got, want), want
+
+    e1, w1 = both(seeded_state(ref, seed=0))
+    e2, w2 = both(seeded_state_other(ref))
+    assert e1 < 3e-2 and e2 < 3e-2, (e1, e2)
+    assert rel_err(w1, w2) > 0.1                        # the two checkpoints really differ
+    # in-place edit of one fused operand family without load_state_dict
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_.endswith(("to_q.weight", "ff.net.0.proj.weight", "time_emb_proj.weight", "attn2.to_k.weight")):
+                p_.mul_(0.5)
+        ref.load_state_dict({k: v.float() for k, v in net.state_dict().items()})
+        want = ref(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
+        got = net(i["sample"].half(), i["t"], i["text"].half(), i["cond"].half(), i["mask"].half(), motion=i["motion"]).sample
+    assert rel_err(got, want) < 3e-2
+
+
+def seeded_state_other(module):
+    g = torch.Generator().manual_seed(77)
+    return {k: (torch.randn(v.shape, generator=g) * (0.05 if v.dim() > 1 else 0.3) + (1.0 if "norm" in k and k.endswith("weight") else 0.0))
+            for k, v in module.state_dict().items()}

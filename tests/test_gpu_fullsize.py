@@ -1,0 +1,248 @@
+"""Parity AT THE BENCHMARKED CONFIGURATION (BASELINE.json configs[1]; VERDICT r01 row g): the full v1.02 architecture
+on [2,4,16,64,64] latents (17 frames inside, CFG batch 2) through the product path exactly as bench.py runs it -
+hipGraph replay, autotuned tiles, M = 139 264-row contractions with round splitting / split-K tails, 4096-key attention -
+against the CPU oracle, plus per-op checks at the real shapes against fp32 torch ON THE GPU (F.conv2d, F.group_norm, fp32
+softmax attention).  Reference shapes: /root/reference/models/unet_3d_condition_mask.py:338-526 at SURVEY.md section 3.2 /
+Appendix B sizes.
+
+Tolerances (fp16 storage, fp32 accumulate): whole forward latent MSE < 1e-3 and max-normalised error < 3e-2 (north star);
+per-op max error <= 2e-2 * max(1, |ref|max) like tests/test_kernels.py.
+"""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from animate_anything_amd import ops
+from animate_anything_amd._lib import AA_ACT_SILU
+from util import FULL_UNET, fullsize_inputs, fullsize_oracle, rel_err
+
+pytestmark = pytest.mark.gpu
+DT = torch.float16
+HERE = os.path.dirname(os.path.abspath(__file__))
+B, T, H, W = 2, 17, 64, 64                # clips (CFG), frames inside the UNet, latent size
+N_IMG, HW = B * T, H * W
+M0 = N_IMG * HW                            # 139 264 tokens at the 64x64 level
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device="cuda") * scale).to(DT)
+
+
+def close(a, b, tol=2e-2):
+    a, b = a.float(), b.float()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-6
+    assert math.isfinite(err) and err <= tol * max(1.0, ref), f"max err {err} (ref max {ref})"
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ whole forward
+def test_unet_forward_at_the_metric_configuration():
+    """ONE forward of the benchmarked step, product (hipGraph on, autotune on, second replay compared) vs the oracle."""
+    from animate_anything_amd.unet3d import UNet3DConditionModel
+    fixture = os.path.join(HERE, "golden", "unet_fullsize_16x64x64.pt")
+    ref, state = fullsize_oracle()
+    i = fullsize_inputs(16, 64)
+    if os.path.exists(fixture) and os.environ.get("AA_FULLSIZE_LIVE", "0") != "1":
+        want = torch.load(fixture)["out"].float()          # oracle output, tests/golden/make_fullsize_golden.py
+    else:
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        with torch.no_grad():
+            want = ref(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
+    del ref
+    net = UNet3DConditionModel(**FULL_UNET).eval()
+    net.load_state_dict(state)
+    del state
+    net = net.to(DT).cuda()
+    net.enable_graph()
+    dev = lambda x: x.to(DT).cuda()
+    with torch.no_grad():
+        for _ in range(2):                                   # capture, then a replay
+            got = net(dev(i["sample"]), i["t"], dev(i["text"]), dev(i["cond"]), dev(i["mask"]), motion=i["motion"]).sample
+    torch.cuda.synchronize()
+    got = got.float().cpu()
+    assert got.shape == want.shape == (2, 4, 16, 64, 64)
+    assert torch.isfinite(got).all()
+    mse = ((got - want) ** 2).mean().item()
+    assert mse < 1e-3, mse
+    assert rel_err(got, want) < 3e-2, rel_err(got, want)
+    # the two CFG halves see different text: they must differ (guards against a degenerate all-equal output)
+    assert (got[0] - got[1]).abs().max().item() > 1e-3
+
+
+# ------------------------------------------------------------------------------------------ contractions at real shapes
+@pytest.mark.parametrize("c1", [0, 640])
+def test_conv3x3_320_at_34x64x64(c1):
+    """ResnetBlock2D.conv1 at the 64x64 level: 320->320, and the up-block two-source 960 (=320+640)->320 with the
+    time-embedding row vector and SiLU... (M = 139264, K = 2880 / 8640, round splitting + split-K tail on 256 CUs)."""
+    c0, cout = 320, 320
+    x = rnd(N_IMG, c0 + c1, H, W, seed=1)
+    wt, b = rnd(cout, c0 + c1, 3, 3, scale=0.02, seed=2), rnd(cout, seed=3)
+    temb = rnd(B, cout, seed=4)
+    tok = nhwc(x)
+    x0, x1 = (tok, None) if c1 == 0 else (tok[:, :c0].contiguous(), tok[:, c0:].contiguous())
+    res = rnd(M0, cout, seed=5)
+    y = ops.conv_gemm(x0, ops.pack_weight(wt, b), ops.conv3x3_geom(N_IMG, H, W), x1=x1, rowvec=temb, rowvec_div=T * HW,
+                      residual=res)
+    ref = F.conv2d(x.float(), wt.float(), b.float(), padding=1) + temb.float().repeat_interleave(T, 0)[:, :, None, None]
+    close(y, nhwc(ref).half().float() + res.float())
+
+
+def test_temporal_conv_at_2x17x4096():
+    """TemporalConvLayer Conv3d (3,1,1) at the 64x64 level: a 3x1 implicit GEMM over [clips, frames, pixels], + identity."""
+    c = 320
+    x5 = rnd(B, c, T, HW, 1, seed=6)
+    wt, b = rnd(c, c, 3, 1, 1, scale=0.03, seed=7), rnd(c, seed=8)
+    tok = x5.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous()
+    y = ops.conv_gemm(tok, ops.pack_weight(wt, b), ops.tconv_geom(B, T, HW), residual=tok)
+    ref = F.conv3d(x5.float(), wt.float(), b.float(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, c)
+    close(y, ref.half().float() + tok.float())
+
+
+def test_geglu_and_ff_out_at_139264():
+    """FeedForward of a 64x64-level transformer block: GEGLU 320->2560 (value*gelu(gate)) then Linear 1280->320 + residual."""
+    x = rnd(M0, 320, seed=9)
+    w1, b1 = rnd(2560, 320, scale=0.05, seed=10), rnd(2560, seed=11)
+    w2, b2 = rnd(320, 1280, scale=0.03, seed=12), rnd(320, seed=13)
+    h = ops.conv_gemm(x, ops.pack_weight(w1, b1, geglu=True), ops.linear_geom(M0))
+    p = x.float() @ w1.float().t() + b1.float()
+    href = p[:, :1280] * F.gelu(p[:, 1280:])
+    close(h, href)
+    y = ops.conv_gemm(h, ops.pack_weight(w2, b2), ops.linear_geom(M0), residual=x)
+    close(y, (h.float() @ w2.float().t() + b2.float()).half().float() + x.float())
+
+
+def test_linear_640_at_34816_and_1280_at_8704():
+    """Attention out-projections (+residual) of the 32x32 and 16x16 levels (the autotuned 128- / 192-row tiles)."""
+    for m, c, seed in ((34816, 640, 14), (8704, 1280, 17), (2176, 1280, 20)):
+        x, w, b = rnd(m, c, seed=seed), rnd(c, c, scale=0.03, seed=seed + 1), rnd(c, seed=seed + 2)
+        y = ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(m), residual=x)
+        close(y, (x.float() @ w.float().t() + b.float()).half().float() + x.float())
+
+
+def test_conv3x3_1280_at_16x16_and_8x8_split_k():
+    """Long-K convolutions of the small levels (few tiles: the K loop is split over workgroups, fp32 partials + reduce)."""
+    for hw, c0, c1, seed in ((16, 1280, 0, 23), (8, 1280, 1280, 26)):
+        x = rnd(N_IMG, c0 + c1, hw, hw, seed=seed)
+        wt, b = rnd(1280, c0 + c1, 3, 3, scale=0.01, seed=seed + 1), rnd(1280, seed=seed + 2)
+        tok = nhwc(x)
+        x0, x1 = (tok, None) if c1 == 0 else (tok[:, :c0].contiguous(), tok[:, c0:].contiguous())
+        y = ops.conv_gemm(x0, ops.pack_weight(wt, b), ops.conv3x3_geom(N_IMG, hw, hw), x1=x1, act=AA_ACT_SILU)
+        close(y, nhwc(F.silu(F.conv2d(x.float(), wt.float(), b.float(), padding=1))))
+
+
+# ------------------------------------------------------------------------------------------ attention at real shapes
+def sdpa32(q, k, v):
+    return F.scaled_dot_product_attention(q.float(), k.float(), v.float())
+
+
+def test_spatial_attention_34x5x4096():
+    """Spatial self-attention of the 64x64 level: 34 images x 5 heads x 4096 queries x 4096 keys (64 ring tiles)."""
+    heads, C = 5, 320
+    qkv = rnd(M0, 3 * C, seed=30)
+    o = ops.attention(qkv, 0, qkv, C, qkv, 2 * C, heads, N_IMG, 1, HW, HW, (HW, 0, 1), (HW, 0, 1))
+    x = qkv.reshape(N_IMG, HW, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    for n0 in range(0, N_IMG, 17):                         # fp32 reference in two chunks (memory)
+        ref = sdpa32(x[0, n0:n0 + 17], x[1, n0:n0 + 17], x[2, n0:n0 + 17]).permute(0, 2, 1, 3).reshape(-1, C)
+        close(o[n0 * HW:(n0 + 17) * HW], ref, tol=1e-2)
+
+
+def test_spatial_attention_peaked_scores_4096():
+    """Online-softmax rescale path at full length: scores with a large spread and row maxima that keep moving."""
+    heads, C, n = 1, 64, 2
+    q = rnd(n * HW, C, scale=4.0, seed=31)
+    kv = rnd(n * HW, 2 * C, scale=1.0, seed=32)
+    kv[:, :C] *= torch.linspace(0.2, 4.0, n * HW, device="cuda", dtype=DT)[:, None]      # later keys score higher
+    o = ops.attention(q, 0, kv, 0, kv, C, heads, n, 1, HW, HW, (HW, 0, 1), (HW, 0, 1))
+    ref = sdpa32(q.reshape(n, 1, HW, 64), kv[:, :C].reshape(n, 1, HW, 64), kv[:, C:].reshape(n, 1, HW, 64)).reshape(-1, C)
+    close(o, ref, tol=1e-2)
+
+
+def test_cross_attention_text_at_64x64():
+    heads, C, Lt = 5, 320, 77
+    q = rnd(M0, C, seed=33)
+    kv = rnd(B * Lt, 2 * C, seed=34)
+    o = ops.attention(q, 0, kv, 0, kv, C, heads, N_IMG, 1, HW, Lt, (HW, 0, 1), (Lt, 0, 1), kv_outer_div=T)
+    qq = q.reshape(B, T, HW, heads, 64).permute(0, 1, 3, 2, 4)
+    kk = kv.reshape(B, 1, Lt, 2, heads, 64).permute(3, 0, 1, 4, 2, 5)
+    ref = sdpa32(qq, kk[0].expand(B, T, heads, Lt, 64), kk[1].expand(B, T, heads, Lt, 64)).permute(0, 1, 3, 2, 4).reshape(-1, C)
+    close(o, ref, tol=1e-2)
+
+
+def test_temporal_attention_8192x17():
+    """Temporal self-attention of the 64x64 level: 2 clips x 4096 pixels = 8192 sequences of 17 frames, rows strided by H*W."""
+    heads, C = 5, 320
+    qkv = rnd(M0, 3 * C, seed=35)
+    st = (T * HW, 1, HW)
+    o = ops.attention(qkv, 0, qkv, C, qkv, 2 * C, heads, B, HW, T, T, st, st)
+    x = qkv.reshape(B, T, HW, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)                 # [3,b,hw,h,T,d]
+    ref = sdpa32(x[0], x[1], x[2]).permute(0, 3, 1, 2, 4).reshape(-1, C)               # -> [b,T,hw,h,d]
+    close(o, ref, tol=1e-2)
+
+
+# ------------------------------------------------------------------------------------------ norms at real shapes
+@pytest.mark.parametrize("c0,c1,hw,frames", [(640, 320, 64, 1), (1280, 1280, 16, 1), (320, 0, 64, 17), (1280, 0, 8, 17)])
+def test_groupnorm_real_shapes(c0, c1, hw, frames):
+    """Two-source GroupNorm(+SiLU) of the up-block resnets (960 ch x 4096 tokens, 2560 ch x 256 tokens) and the clip-wide
+    (C/32, T, H, W) statistics of TemporalConvLayer / TransformerTemporalModel."""
+    C = c0 + c1
+    n = N_IMG
+    x = rnd(n, C, hw * hw, 1, seed=40) * 1.5 + 0.3
+    gamma, beta = rnd(C, seed=41), rnd(C, seed=42)
+    tok = nhwc(x)
+    x0, x1 = (tok, None) if c1 == 0 else (tok[:, :c0].contiguous(), tok[:, c0:].contiguous())
+    y = ops.groupnorm(x0, gamma, beta, n // frames, frames * hw * hw, 32, eps=1e-5, silu=True, x1=x1)
+    x5 = x.float().reshape(n // frames, frames, C, hw * hw).permute(0, 2, 1, 3)
+    ref = F.silu(F.group_norm(x5, 32, gamma.float(), beta.float(), 1e-5)).permute(0, 2, 3, 1).reshape(-1, C)
+    close(y, ref)
+
+
+def test_groupnorm_large_mean_small_spread():
+    """Activations of real checkpoints are not zero-mean: a group with mean 50, std 1 (fp16 storage) must not lose its
+    variance to cancellation (the statistics are centred on a per-group pivot, not E[x^2] - mean^2 on raw values)."""
+    C, hw, n = 320, 4096, 4
+    x = (torch.randn(n, C, hw, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(43)) + 50.0).to(DT)
+    gamma, beta = torch.ones(C, device="cuda", dtype=DT), torch.zeros(C, device="cuda", dtype=DT)
+    y = ops.groupnorm(nhwc(x), gamma, beta, n, hw, 32, eps=1e-5, silu=False)
+    ref = nhwc(F.group_norm(x.float(), 32, None, None, 1e-5))
+    close(y, ref, tol=1e-2)
+    assert abs(y.float().std().item() - 1.0) < 2e-2
+
+
+def test_layernorm_at_139264x320():
+    x, g, b = rnd(M0, 320, seed=44) * 2 + 0.5, rnd(320, seed=45), rnd(320, seed=46)
+    close(ops.layernorm(x, g, b, 1e-5), F.layer_norm(x.float(), (320,), g.float(), b.float(), 1e-5))
+
+
+# ------------------------------------------------------------------------------------------ VAE at the SD configuration
+def test_full_size_vae_decode_and_encode_one_frame():
+    """AutoencoderKL with the SD/ModelScope config (128/256/512/512) on ONE 512x512 frame (64x64 latent) vs the oracle."""
+    import oracle
+    from animate_anything_amd.vae import AutoencoderKL
+    from util import seeded_state
+    torch.manual_seed(0)
+    ref = oracle.AutoencoderKL().eval()
+    state = seeded_state(ref)
+    ref.load_state_dict(state)
+    vae = AutoencoderKL().eval()
+    vae.load_state_dict(state)
+    vae = vae.half().cuda()
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(1, 4, 64, 64, generator=g)
+    img = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        want = ref.decode(z).sample
+        got = vae.decode(z.half().cuda()).sample
+        assert got.shape == want.shape == (1, 3, 512, 512)
+        assert rel_err(got, want) < 2e-2
+        want_z = ref.encode(img).latent_dist.mode()
+        got_z = vae.encode(img.half().cuda()).latent_dist.mode()
+        assert rel_err(got_z, want_z) < 2e-2

@@ -135,6 +135,19 @@ def test_groupnorm(backend, c0, c1, groups, frames):
     close(y, ref)
 
 
+def test_groupnorm_large_mean(backend):
+    """mean 50, std 1 in fp16 storage: the statistics are accumulated centred on a per-group pivot, so the variance
+    survives (E[x^2] - mean^2 on the raw values would lose ~3 decimal digits to cancellation in fp32)."""
+    n, C, hw, groups = 2, 64, 300, 8
+    g = torch.Generator().manual_seed(131)
+    x = (torch.randn(n, C, hw, 1, generator=g) + 50.0).to(DT).to(DEV)
+    x[:, 32:] -= 120.0                                    # other groups sit at -70
+    gamma, beta = torch.ones(C, dtype=DT, device=DEV), torch.zeros(C, dtype=DT, device=DEV)
+    y = ops.groupnorm(nhwc(x), gamma, beta, n, hw, groups, eps=1e-5, silu=False)
+    ref = nhwc(F.group_norm(x.float().cpu(), groups, None, None, 1e-5))
+    close(y, ref, tol=5e-3)
+
+
 @pytest.mark.parametrize("C", [64, 320, 640, 1280])
 def test_layernorm(backend, C):
     x, g, b = rnd(11, C, seed=28) * 3 + 1, rnd(C, seed=29), rnd(C, seed=30)

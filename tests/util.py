@@ -36,3 +36,29 @@ def unet_inputs(b=2, frames=2, h=6, w=6, text_len=77, text_dim=64, seed=1234):
 def rel_err(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return ((a - b).abs().max() / (b.abs().max() + 1e-6)).item()
+
+
+# ---------------------------------------------------------------------------- metric configuration (BASELINE.json configs[1])
+FULL_UNET = dict(motion_mask=True, motion_strength=True)        # the v1.02 architecture: every other ctor default
+
+
+def fullsize_inputs(frames=16, lat=64, seed=1234):
+    """One CFG-doubled UNet call of the benchmarked step (same construction as bench.py `synthetic_inputs` +
+    `LatentToVideoPipeline.denoise`): sample [2,4,frames,lat,lat], cond [2,4,1,lat,lat], text [2,77,1024] = [neg; text]."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    mask = torch.zeros(1, 1, 1, lat, lat)
+    mask[..., lat // 4: lat - lat // 4, lat // 4: lat - lat // 4] = 1
+    latents, cond, text, neg = r(1, 4, frames, lat, lat), r(1, 4, 1, lat, lat), r(1, 77, 1024), r(1, 77, 1024)
+    return dict(sample=torch.cat([latents, latents]), cond=torch.cat([cond, cond]), mask=mask,
+                text=torch.cat([neg, text]), motion=torch.tensor([3.0]), t=951)
+
+
+def fullsize_oracle():
+    """The full architecture with seeded weights (fp32, CPU); returns (module, state dict)."""
+    import oracle
+    torch.manual_seed(0)
+    ref = oracle.UNet3DConditionModel(**FULL_UNET).eval()
+    state = seeded_state(ref)
+    ref.load_state_dict(state)
+    return ref, state
