@@ -64,6 +64,15 @@ static const CgCfg kCgCfgs[] = {
     {192, 256, 2, 4, 64, 2, 1, 1.05f},    // 23 eight waves of 96x64: 230 tiles for the 8704-row (16x16) level = one 90 % round
     {192, 256, 2, 4, 64, 2, 1, 1.05f},    // 24 staggered
     {128, 256, 2, 4, 32, 2, 2, 1.00f},    // 25 eight waves of 64x64, two workgroups per CU
+    // "spread": every wave issues its DMA share of the next tile in pieces in front of the k sub-steps of its multiply
+    {256, 320, 4, 2, 64, 2, 1, 1.30f},    // 26 spread
+    {256, 256, 4, 2, 64, 2, 1, 1.25f},    // 27 spread
+    {192, 256, 2, 4, 64, 2, 1, 1.05f},    // 28 spread
+    {256, 320, 4, 2, 32, 4, 1, 1.20f},    // 29 spread, deep ring
+    {128, 320, 2, 2, 32, 2, 2, 1.10f},    // 30 spread, two workgroups per CU
+    {128, 128, 2, 2, 64, 2, 2, 0.90f},    // 31 spread
+    {192, 320, 3, 2, 64, 2, 1, 1.05f},    // 32 spread
+    {128, 256, 2, 2, 32, 2, 2, 1.05f},    // 33 spread
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -167,11 +176,11 @@ static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) 
     return p;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER = false>
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER = false, bool SPREAD = false>
 static void cg_launch_dma(const AaConvGemm& d, int m_begin, int m_end, int splits, void* stream) {
     const int tiles_n = d.n_pad / BN;
     const dim3 grid(((m_end - m_begin + BM - 1) / BM) * tiles_n, splits), block(64 * WM * WN);
-    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES, PER_CU, STAGGER>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, m_end, tiles_n, m_begin, splits);
+    AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES, PER_CU, STAGGER, SPREAD>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, m_end, tiles_n, m_begin, splits);
 }
 
 template <typename T>
@@ -203,6 +212,14 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 23: cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
         case 24: cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1, true>(d, m_begin, m_end, splits, stream); break;
         case 25: cg_launch_dma<T, 128, 256, 2, 4, 32, 2, 2>(d, m_begin, m_end, splits, stream); break;
+        case 26: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream); break;
+        case 27: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream); break;
+        case 28: cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream); break;
+        case 29: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1, false, true>(d, m_begin, m_end, splits, stream); break;
+        case 30: cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2, false, true>(d, m_begin, m_end, splits, stream); break;
+        case 31: cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2, false, true>(d, m_begin, m_end, splits, stream); break;
+        case 32: cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream); break;
+        case 33: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2, false, true>(d, m_begin, m_end, splits, stream); break;
         default: return false;
     }
     return true;

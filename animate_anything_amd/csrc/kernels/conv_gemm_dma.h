@@ -31,7 +31,9 @@ __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages)
 }
 
 // PER_CU = workgroups meant to be co-resident on a CU (register budget: 512 / (PER_CU * waves per SIMD)).
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER>
+// SPREAD: a wave's DMA share of the next tile is not issued in one burst but in pieces in front of the first k sub-steps of
+// its multiply (each piece queues in the CU-wide LDS-DMA issue path while the wave's previous MFMAs still occupy the matrix pipe).
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int PER_CU, bool STAGGER, bool SPREAD = false>
 __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv_gemm_dma_kernel(const AaConvGemm p, const int M, const int tiles_n, const int m_begin, const int k_splits) {
     // rows [m_begin, M) of the output are tiled by this launch (a launch may cover only part of the rows:
     // the host splits off a sparsely filled last round of big tiles and runs it with small tiles)
@@ -161,7 +163,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     }
     int cur_tap = -1;
     unsigned pb0[AJ], pb1[AJ];           // byte offset of each fed row's source pixel for the current tap (OOB = halo / tail)
-    auto issue = [&](int kt, int buf) {
+    // state of the tile being issued (issue_prepare -> issue_dma pieces)
+    bool is_src1 = false;
+    unsigned is_ccb = 0u, is_kb = 0u;
+    int is_buf = 0;
+    auto issue_prepare = [&](int kt, int buf) {
         const int tap = n_tap, cb = n_cb, dy = n_dy, dx = n_dx;
         // advance to the next K tile (selects, not `++x` in branches: those get tail-merged into one increment through
         // a selected POINTER, which pins the counters in scratch)
@@ -217,24 +223,35 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
                 }
             }
         }
-        const bool src1 = cb >= p.c0;
-        const unsigned ccb = (unsigned)(src1 ? cb - p.c0 : cb) * 2u;
-        const BufRsrc ra = src1 ? r_a1 : r_a0;
-        char* a = smem + buf * STAGE_BYTES + wave * RPI * ROWB;
-        char* b = smem + buf * STAGE_BYTES + BM * ROWB + wave * RPI * ROWB;
-        // every wave issues exactly PER_TILE instructions (vmcnt bookkeeping): groups past the tile edge read
-        // out of range and land in the dummy zone (wave-uniform choice)
+        is_src1 = cb >= p.c0;
+        is_ccb = (unsigned)(is_src1 ? cb - p.c0 : cb) * 2u;
+        is_kb = (unsigned)((kbase + kt) * BK) * 2u;
+        is_buf = buf;
+    };
+    // DMA instructions [J0, J1) of the prepared tile: indices < AJ feed activation rows, the rest weight rows.
+    // every wave issues exactly PER_TILE instructions per tile (vmcnt bookkeeping): groups past the tile edge read
+    // out of range and land in the dummy zone (wave-uniform choice)
+    auto issue_dma = [&](auto j0_, auto j1_) {
+        constexpr int J0 = decltype(j0_)::value, J1 = decltype(j1_)::value;
+        const BufRsrc ra = is_src1 ? r_a1 : r_a0;
+        char* a = smem + is_buf * STAGE_BYTES + wave * RPI * ROWB;
+        char* b = smem + is_buf * STAGE_BYTES + BM * ROWB + wave * RPI * ROWB;
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            const bool real = (GA % NW == 0) || (wave + NW * j < GA);
-            async_copy16_buf(ra, (real && !dry) ? (src1 ? pb1[j] : pb0[j]) + ccb : OOB, real ? a + j * NW * RPI * ROWB : dummy);
+        for (int jj = J0; jj < J1; ++jj) {
+            if (jj < AJ) {
+                const int j = jj;
+                const bool real = (GA % NW == 0) || (wave + NW * j < GA);
+                async_copy16_buf(ra, (real && !dry) ? (is_src1 ? pb1[j] : pb0[j]) + is_ccb : OOB, real ? a + j * NW * RPI * ROWB : dummy);
+            } else {
+                const int j = jj - AJ;
+                const bool real = (GB % NW == 0) || (wave + NW * j < GB);
+                async_copy16_buf(r_w, (real && !dry) ? wb[j] + is_kb : OOB, real ? b + j * NW * RPI * ROWB : dummy);
+            }
         }
-        const unsigned kb = (unsigned)((kbase + kt) * BK) * 2u;
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const bool real = (GB % NW == 0) || (wave + NW * j < GB);
-            async_copy16_buf(r_w, (real && !dry) ? wb[j] + kb : OOB, real ? b + j * NW * RPI * ROWB : dummy);
-        }
+    };
+    auto issue = [&](int kt, int buf) {
+        issue_prepare(kt, buf);
+        issue_dma(IntTag<0>(), IntTag<PER_TILE>());
     };
 
     f32x16 acc[MI][NI];
@@ -263,6 +280,17 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     auto frag_ptr_a = [&](const char* st, int ks, int i) { return st + a_off[i] + (((ks * 2 + fh) ^ a_swz[i]) << 4); };
     auto frag_ptr_b = [&](const char* st, int ks, int j) { return st + b_off[j] + (((ks * 2 + fh) ^ b_swz[j]) << 4); };
     constexpr int KS = BK / 16;
+    // SPREAD: the pieces go in front of the first SP sub-steps (the last sub-step of a 2-stage ring stays free: its data
+    // would have too little time to land before the next barrier)
+    constexpr int SP = (KS >= 4 && STAGES == 2) ? KS - 1 : KS;
+    auto issue_piece = [&](auto ks_, int kt_next) {
+        constexpr int ks = decltype(ks_)::value;
+        if constexpr (ks < SP) {
+            constexpr int J0 = PER_TILE * ks / SP, J1 = PER_TILE * (ks + 1) / SP;
+            if constexpr (ks == 0) issue_prepare(kt_next, kt_next % STAGES);
+            issue_dma(IntTag<J0>(), IntTag<J1>());
+        }
+    };
     // multiply K tile `buf`; before sub-step `issue_at` the wave issues its DMA share of tile `kt_next` (if any)
     auto compute = [&](int buf, int issue_at, int kt_next, bool more) {
         const char* st = smem + buf * STAGE_BYTES;
@@ -275,11 +303,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
                 for (int j = 0; j < NI; ++j) lds_read16_async(fb[set][j], frag_ptr_b(st, ks, j));
             };
             issue_frags(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int set = ks & 1;
-                if (more && ks == issue_at) issue(kt_next, kt_next % STAGES);
-                if (ks + 1 < KS) { issue_frags(ks + 1, set ^ 1); lds_wait<MI + NI>(fa[set][0]); }
+            auto substep = [&](auto ks_) __attribute__((always_inline)) {
+                constexpr int ks = decltype(ks_)::value;
+                constexpr int set = ks & 1;
+                if constexpr (SPREAD) { if (more) issue_piece(ks_, kt_next); }
+                else if (more && ks == issue_at) issue(kt_next, kt_next % STAGES);
+                if constexpr (ks + 1 < KS) { issue_frags(ks + 1, set ^ 1); lds_wait<MI + NI>(fa[set][0]); }
                 else lds_wait<0>(fa[set][0]);
 #pragma unroll
                 for (int i = 1; i < MI; ++i) lds_pin(fa[set][i]);
@@ -289,11 +318,20 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) acc[i][j] = mfma_32x32x16(T(), fb[set][j], fa[set][i], acc[i][j]);
-            }
+            };
+            substep(IntTag<0>());
+            substep(IntTag<1>());
+            if constexpr (KS == 4) { substep(IntTag<2>()); substep(IntTag<3>()); }
         } else {
+            auto piece = [&](auto ks_) __attribute__((always_inline)) { if constexpr (SPREAD) { if (more) issue_piece(ks_, kt_next); } };
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if (more && ks == issue_at) issue(kt_next, kt_next % STAGES);
+                if constexpr (SPREAD) {
+                    if (ks == 0) piece(IntTag<0>());
+                    if (ks == 1) piece(IntTag<1>());
+                    if (KS == 4 && ks == 2) piece(IntTag<2>());
+                    if (KS == 4 && ks == 3) piece(IntTag<3>());
+                } else if (more && ks == issue_at) issue(kt_next, kt_next % STAGES);
                 u32x4 fa[MI], fb[NI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const u32x4*>(frag_ptr_a(st, ks, i));
