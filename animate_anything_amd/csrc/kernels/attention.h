@@ -15,7 +15,11 @@
 //    fragment of O^T needs, for row d, 8 consecutive keys - a column of V - which gfx950's transposing LDS read
 //    delivers directly: one `ds_read_b64_tr_b16` hands lane l of a 16-lane group V[k0..k0+3][d0 + l] from a
 //    [4 keys][16 d] block; a 32-lane half reads exactly one 256-byte block = all 64 banks once.
-// Softmax runs in base 2: p = exp2(s*c - m*c), c = scale*log2(e), max taken on raw scores.
+// Softmax runs in base 2 on scores that leave the matrix pipe ready to exponentiate: Q is pre-multiplied by
+// c = scale*log2(e) when it is loaded, and the S^T accumulators START at -m (the running row maximum) instead of zero, so
+// p = exp2(acc) with no multiply / subtract per score.  The maximum is tracked lazily (defer-max): it is only moved - and
+// O, l rescaled - when some row's scores exceed it by more than AT_DEFER (p <= 2^AT_DEFER in between: exact in fp32, and
+// well inside fp16 / bf16 range for the P operand); the first tile always centres on its true row maximum.
 #pragma once
 #include "dev.h"
 #include "aa_mi355.h"
@@ -23,6 +27,7 @@
 namespace aa {
 
 constexpr int AT_KT = 64;                       // keys per tile
+constexpr float AT_DEFER = 6.0f;                // defer-max threshold, in bits (p stays below 2^6 against a stale maximum)
 constexpr int AT_TILE_BYTES = 2 * AT_KT * 128;  // K tile + V tile of one stage
 
 // ring depth: one buffer when the sequence fits a single tile (temporal / text attention), else three
@@ -58,7 +63,7 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
     const int o = seq / p.n_inner, i = seq - o * p.n_inner;
     const int q0 = (blockIdx.x * NW + wave) * 32;
     const bool wave_active = q0 < p.q_len;
-    const float sl2e = p.scale * 1.4426950408889634f;
+    const float sl2e = p.scale * 1.4426950408889634f;   // folded into Q: scores are in base-2 exponent units
 
     // Q fragment: B operand of S^T (col = query, k = d)
     u32x4 qf[4];
@@ -68,9 +73,12 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
         const T* src = attn_row<T>(p.q, o, i, ok ? q : 0, head) + 8 * h;
 #pragma unroll
         for (int dk = 0; dk < 4; ++dk) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4*>(src + 16 * dk);
-            qf[dk] = v;
+            Pack8<T> v;
+            v.raw = u32x4{0u, 0u, 0u, 0u};
+            if (ok) v.raw = *reinterpret_cast<const u32x4*>(src + 16 * dk);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.e[e] = (T)((float)v.e[e] * sl2e);      // scores come out in units of bits
+            qf[dk] = v.raw;
         }
     }
 
@@ -117,7 +125,7 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
     f32x16 oacc[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.0f; oacc[1][e] = 0.0f; }
-    float m_run = -1.0e30f, l_run = 0.0f;       // running max of RAW scores, running sum of this half-wave's keys
+    float m_run = 0.0f, l_run = 0.0f;           // running (lazily moved) max of the scaled scores, running sum of this half-wave's keys
 
     const int ntiles = (p.kv_len + AT_KT - 1) / AT_KT;
     const bool ragged = (p.kv_len & (AT_KT - 1)) != 0;
@@ -134,9 +142,11 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
         if (wave_active) {
             const char* sK = lds + (stages == 1 ? 0 : (kt % 3)) * AT_TILE_BYTES;
             const char* sV = sK + AT_KT * 128;
+            // S^T - m: the accumulators start at minus the running maximum (zero for the first tile)
+            const float acc0 = kt == 0 ? 0.0f : -m_run;
             f32x16 sacc[2];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { sacc[0][e] = 0.0f; sacc[1][e] = 0.0f; }
+            for (int e = 0; e < 16; ++e) { sacc[0][e] = acc0; sacc[1][e] = acc0; }
             // the two 32-key blocks alternate so that consecutive MFMAs never wait on each other's accumulator
 #pragma unroll
             for (int dk = 0; dk < 4; ++dk)
@@ -154,7 +164,7 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
                         if (key >= p.kv_len) sacc[kb][e] = -1.0e30f;
                     }
             }
-            // row max: four independent chains, then a tree (a single 32-long fmax chain is pure latency)
+            // row max of (score - m): four independent chains, then a tree (a single 32-long fmax chain is pure latency)
             float mx[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) mx[c] = fmaxf(sacc[c >> 1][8 * (c & 1)], sacc[c >> 1][8 * (c & 1) + 1]);
@@ -162,16 +172,21 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
             for (int e = 2; e < 8; ++e)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) mx[c] = fmaxf(mx[c], sacc[c >> 1][8 * (c & 1) + e]);
-            const float mloc = wave_max_halves(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
-            const float m_new = fmaxf(m_run, mloc);
-            if (wave_any(m_new > m_run)) {              // some row's max moved: rescale the accumulators
-                const float alpha = fast_exp2((m_run - m_new) * sl2e);
-                l_run *= alpha;
+            const float over = wave_max_halves(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
+            if (kt == 0 || wave_any(over > AT_DEFER)) {
+                // move the maximum (rare after the first tiles): everything still at the old maximum - O, l and this tile's
+                // scores, which have NOT been exponentiated yet - is rescaled exactly once
+                const float delta = kt == 0 ? over : fmaxf(over, 0.0f);
+                m_run += delta;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
-                m_run = m_new;
+                for (int e = 0; e < 16; ++e) { sacc[0][e] -= delta; sacc[1][e] -= delta; }
+                if (kt != 0) {
+                    const float alpha = fast_exp2(-delta);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+                }
             }
-            const float nmc = -m_run * sl2e;
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 ps2[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};      // packed partial row sums
             u32x4 pf[4];
@@ -183,8 +198,8 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         f32x2 pe;
-                        pe[0] = fast_exp2(__builtin_fmaf(sacc[kb][8 * c + e], sl2e, nmc));       // one v_fma + one v_exp per score
-                        pe[1] = fast_exp2(__builtin_fmaf(sacc[kb][8 * c + e + 1], sl2e, nmc));
+                        pe[0] = fast_exp2(sacc[kb][8 * c + e]);                  // one v_exp per score
+                        pe[1] = fast_exp2(sacc[kb][8 * c + e + 1]);
                         ps2[2 * kb + c] += pe;
                         pk.e[e] = (T)pe[0];
                         pk.e[e + 1] = (T)pe[1];

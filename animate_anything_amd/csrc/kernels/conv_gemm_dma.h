@@ -51,7 +51,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     constexpr int PER_TILE = AJ + BJ;                    // every wave issues exactly this many per tile
     constexpr int DIST = STAGES - 1;                     // tiles in flight ahead of the multiply
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
-    constexpr bool FRAG_ASM = (MI * NI * 16 + 2 * (MI + NI) * 4) <= 184;   // accumulators + two fragment sets fit beside the rest
+    // accumulators + two fragment sets fit beside the rest.  (One-wave-per-SIMD tiles with 128x160 per wave - 0.45 LDS
+    // fragment reads per MFMA instead of 0.7 - need the accumulators in AGPRs beyond 256 registers: hipcc keeps them in
+    // VGPRs and spills 2.4 KB of scratch instead; measured unusable, not in the table.)
+    constexpr bool FRAG_ASM = (MI * NI * 16 + 2 * (MI + NI) * 4) <= 184;
     static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % RPI == 0 && BN % RPI == 0, "tile shape");
     static_assert(BK == 64 || BK == 32, "K step");
     static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * PER_TILE <= 63, "pipeline depth");
@@ -287,8 +290,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         constexpr int ks = decltype(ks_)::value;
         if constexpr (ks < SP) {
             constexpr int J0 = PER_TILE * ks / SP, J1 = PER_TILE * (ks + 1) / SP;
-            if constexpr (ks == 0) issue_prepare(kt_next, kt_next % STAGES);
-            issue_dma(IntTag<J0>(), IntTag<J1>());
+            issue_dma(IntTag<J0>(), IntTag<J1>());        // (the tile was prepared at the end of the previous K step)
         }
     };
     // multiply K tile `buf`; before sub-step `issue_at` the wave issues its DMA share of tile `kt_next` (if any)
@@ -359,6 +361,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 #pragma unroll
         for (int t = 0; t < DIST; ++t)
             if (t < nk) issue(t, t);
+        // SPREAD: the address arithmetic of the NEXT tile to issue (K position, per-row tap offsets) runs at the END of a K
+        // step - behind the wave's last MFMAs, in time it would otherwise spend at the barrier - not at its start
+        if constexpr (SPREAD) { if (DIST < nk) issue_prepare(DIST, DIST % STAGES); }
         for (int kt = 0; kt < nk; ++kt) {
             // tile kt must have landed; the (up to DIST-1) younger tiles may stay in flight
             const int younger = min(nk, kt + DIST) - (kt + 1);
@@ -376,6 +381,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             const bool more = kt + DIST < nk && !(p.debug & 1);
             if (!(p.debug & 2)) compute(kt % STAGES, issue_at, kt + DIST, more);
             else if (more) issue(kt + DIST, (kt + DIST) % STAGES);
+            if constexpr (SPREAD) { if (kt + 1 + DIST < nk) issue_prepare(kt + 1 + DIST, (kt + 1 + DIST) % STAGES); }
             AA_TICK(3)
         }
     }
@@ -455,40 +461,47 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
                 if (m_ok && nc + 8 * q + 8 <= n_cols) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o[q].raw;
             }
         };
-        auto block_vals = [&](int j, Pack8<T> (&o)[2]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU), rounded to storage type
+        auto block_f32 = [&](int j, float (&v)[2][8]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU) in fp32
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 Pack8<T> b; b.raw = *reinterpret_cast<const u32x4*>(sBias + (wn * (BN / WN) + j * 32 + 16 * eh + 8 * q));
                 const u32x4 pv = pre[j][q];
                 Pack8<T> r; r.raw = AA_ZERO4;
                 if (pre_is_rv) r.raw = pv;
-                float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * q + e] + (float)b.e[e] + brow;
+                for (int e = 0; e < 8; ++e) v[q][e] = acc[i][j][8 * q + e] + (float)b.e[e] + brow;
                 if (pre_is_rv) {                          // uniform branches once per eight values, not once per value
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)r.e[e];
+                    for (int e = 0; e < 8; ++e) v[q][e] += (float)r.e[e];
                 }
                 if (silu) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                    for (int e = 0; e < 8; ++e) v[q][e] = silu_f(v[q][e]);
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[q].e[e] = (T)v[e];
             }
+        };
+        auto block_vals = [&](int j, Pack8<T> (&o)[2]) __attribute__((always_inline)) {     // ... rounded to the storage type
+            float v[2][8];
+            block_f32(j, v);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[q].e[e] = (T)v[q][e];
         };
         if (p.geglu) {
             if constexpr (NI % 2 == 0) {
 #pragma unroll
                 for (int j = 0; j < NI; j += 2) {
-                    Pack8<T> val[2], gate[2];
-                    block_vals(j, val);
-                    block_vals(j + 1, gate);
+                    // value * gelu(gate) in fp32 on the accumulators, ONE rounding to the storage type
+                    float val[2][8], gate[2][8];
+                    block_f32(j, val);
+                    block_f32(j + 1, gate);
+                    Pack8<T> h[2];
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) val[q].e[e] = (T)((float)val[q].e[e] * gelu_erf_f((float)gate[q].e[e]));
-                    finish_block(j, val);
+                        for (int e = 0; e < 8; ++e) h[q].e[e] = (T)(val[q][e] * gelu_erf_f(gate[q][e]));
+                    finish_block(j, h);
                 }
             }
         } else {

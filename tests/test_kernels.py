@@ -181,6 +181,25 @@ def test_attention_ring(backend, Lq, Lkv):
     close(o, ref, tol=1e-2)
 
 
+@pytest.mark.parametrize("Lq,Lkv,qs", [(70, 300, 2.0), (40, 200, 0.3), (33, 77, 3.0)])
+def test_attention_deferred_max(backend, Lq, Lkv, qs):
+    """The running maximum is moved lazily (only when a row's scores exceed it by > 2^6): inputs that FORCE the rescale
+    branch at chosen tiles - widely spread scores (the maximum keeps jumping), one key that spikes against one query deep in
+    the sequence, and rows whose first tile holds only very negative scores - against a full fp32 reference; plus a quiet
+    case (small scores) where the branch is never taken after the first tile."""
+    n = 2
+    q = rnd(n * Lq, 64, scale=qs, seed=141)
+    kv = rnd(n * Lkv, 128, scale=2.0, seed=142)
+    kk = kv.reshape(n, Lkv, 2, 64)
+    qq = q.reshape(n, Lq, 64)
+    kk[0, Lkv - 70, 0] = (qq[0, 5].float() * 4.0).to(DT)               # spike: query 5 of sequence 0 vs a key in a late tile
+    kk[1, :64, 0] = (-qq[1, 7].float().sign() * 3.0).to(DT)            # query 7 of sequence 1: first tile far below the rest
+    o = ops.attention(q, 0, kv, 0, kv, 64, 1, n, 1, Lq, Lkv, (Lq, 0, 1), (Lkv, 0, 1))
+    ref = sdpa(q.reshape(n, 1, Lq, 64), kk[:, :, 0].reshape(n, 1, Lkv, 64), kk[:, :, 1].reshape(n, 1, Lkv, 64)).reshape(n * Lq, 64)
+    assert torch.isfinite(o.float()).all()
+    close(o, ref, tol=1e-2)
+
+
 def test_attention_cross_text(backend):
     clips, frames, heads, L, Lt = 2, 2, 1, 40, 77
     C = heads * 64
