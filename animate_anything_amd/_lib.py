@@ -62,8 +62,28 @@ class AaDpmStep(C.Structure):
     ]
 
 
+class AaPackLatents(C.Structure):
+    _fields_ = [
+        ("sample", C.c_void_p), ("cond", C.c_void_p), ("mask", C.c_void_p), ("out", C.c_void_p),
+        ("batch", C.c_int32), ("sample_batch", C.c_int32), ("cond_batch", C.c_int32), ("mask_batch", C.c_int32),
+        ("channels", C.c_int32), ("frames", C.c_int32), ("hw", C.c_int32), ("dtype", C.c_int32), ("sample_dtype", C.c_int32),
+    ]
+
+
+class AaDpmStepTok(C.Structure):
+    _fields_ = [
+        ("eps_tokens", C.c_void_p), ("latents", C.c_void_p), ("x0_prev", C.c_void_p), ("latents_lp", C.c_void_p),
+        ("next_t", C.c_void_p), ("next_t_count", C.c_int32), ("next_t_value", C.c_float),
+        ("clips", C.c_int32), ("channels", C.c_int32), ("frames", C.c_int32), ("hw", C.c_int32),
+        ("eps_ld", C.c_int32), ("guidance_on", C.c_int32),
+        ("guidance", C.c_float), ("sigma_s", C.c_float), ("alpha_s", C.c_float),
+        ("c_x", C.c_float), ("c_d0", C.c_float), ("c_d1", C.c_float), ("dtype", C.c_int32),
+    ]
+
+
 SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_groupnorm_workspace", "aa_groupnorm",
-           "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step")
+           "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step",
+           "aa_timestep_embedding", "aa_pack_latents", "aa_cfg_dpm_step_tokens")
 
 DEFAULT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaa_mi355.so")
 
@@ -94,6 +114,9 @@ def bind(path: str) -> C.CDLL:
     lib.aa_attention.argtypes = [C.POINTER(AaAttention), C.c_void_p]
     lib.aa_softmax_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.aa_cfg_dpm_step.argtypes = [C.POINTER(AaDpmStep), C.c_void_p]
+    lib.aa_timestep_embedding.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.aa_pack_latents.argtypes = [C.POINTER(AaPackLatents), C.c_void_p]
+    lib.aa_cfg_dpm_step_tokens.argtypes = [C.POINTER(AaDpmStepTok), C.c_void_p]
     for s in SYMBOLS[4:]:
         if s not in ("aa_groupnorm_workspace", "aa_conv_gemm_workspace"):
             getattr(lib, s).restype = C.c_int

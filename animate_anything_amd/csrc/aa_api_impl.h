@@ -12,6 +12,7 @@
 #include "kernels/conv_gemm_dma.h"
 #include "kernels/norm.h"
 #include "kernels/attention.h"
+#include "kernels/glue.h"
 
 namespace aa {
 
@@ -413,6 +414,47 @@ int aa_cfg_dpm_step(const AaDpmStep* d, void* stream) {
     else if (d->dtype == AA_BF16) AA_LAUNCH((cfg_dpm_step_kernel<bf16_t>), grid, block, 0, stream, *d);
     else return fail(AA_E_DTYPE, "cfg_dpm_step: unsupported dtype %d", d->dtype);
     return finish("cfg_dpm_step");
+}
+
+int aa_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim, int32_t dtype, void* stream) {
+    using namespace aa;
+    if (!t || !out || n <= 0 || dim <= 0 || dim % 2) return fail(AA_E_SHAPE, "timestep_embedding: n=%d dim=%d", n, dim);
+    const dim3 grid((unsigned)((n * (dim / 2) + 255) / 256)), block(256);
+    if (dtype == AA_F16) AA_LAUNCH((timestep_embed_kernel<f16_t>), grid, block, 0, stream, t, (f16_t*)out, n, dim);
+    else if (dtype == AA_BF16) AA_LAUNCH((timestep_embed_kernel<bf16_t>), grid, block, 0, stream, t, (bf16_t*)out, n, dim);
+    else return fail(AA_E_DTYPE, "timestep_embedding: unsupported dtype %d", dtype);
+    return finish("timestep_embedding");
+}
+
+int aa_pack_latents(const AaPackLatents* d, void* stream) {
+    using namespace aa;
+    if (!d || !d->sample || !d->cond || !d->out) return fail(AA_E_SHAPE, "pack_latents: null operand");
+    if (d->batch <= 0 || d->sample_batch <= 0 || d->cond_batch <= 0 || d->frames <= 0 || d->hw <= 0 || d->channels <= 0 ||
+        d->channels + (d->mask ? 1 : 0) > 8 || (d->mask && d->mask_batch <= 0))
+        return fail(AA_E_SHAPE, "pack_latents: bad geometry (batch=%d channels=%d frames=%d hw=%d)", d->batch, d->channels, d->frames, d->hw);
+    if (!aligned16(d->out)) return fail(AA_E_ALIGN, "pack_latents: out must be 16-byte aligned");
+    if (d->sample_dtype != AA_F32 && d->sample_dtype != d->dtype) return fail(AA_E_DTYPE, "pack_latents: sample dtype must be f32 or the storage dtype");
+    int64_t blocks = ((int64_t)d->batch * (d->frames + 1) * d->hw + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (d->dtype == AA_F16) AA_LAUNCH((pack_latents_kernel<f16_t>), grid, block, 0, stream, *d);
+    else if (d->dtype == AA_BF16) AA_LAUNCH((pack_latents_kernel<bf16_t>), grid, block, 0, stream, *d);
+    else return fail(AA_E_DTYPE, "pack_latents: unsupported dtype %d", d->dtype);
+    return finish("pack_latents");
+}
+
+int aa_cfg_dpm_step_tokens(const AaDpmStepTok* d, void* stream) {
+    using namespace aa;
+    if (!d || !d->eps_tokens || !d->latents || !d->x0_prev) return fail(AA_E_SHAPE, "cfg_dpm_step_tokens: null operand");
+    if (d->clips <= 0 || d->channels <= 0 || d->frames <= 0 || d->hw <= 0 || d->eps_ld < d->channels || d->next_t_count < 0 || d->next_t_count > 256)
+        return fail(AA_E_SHAPE, "cfg_dpm_step_tokens: bad geometry");
+    int64_t blocks = ((int64_t)d->clips * d->channels * d->frames * d->hw + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (d->dtype == AA_F16) AA_LAUNCH((cfg_dpm_step_tok_kernel<f16_t>), grid, block, 0, stream, *d);
+    else if (d->dtype == AA_BF16) AA_LAUNCH((cfg_dpm_step_tok_kernel<bf16_t>), grid, block, 0, stream, *d);
+    else return fail(AA_E_DTYPE, "cfg_dpm_step_tokens: unsupported dtype %d", d->dtype);
+    return finish("cfg_dpm_step_tokens");
 }
 
 }  // extern "C"

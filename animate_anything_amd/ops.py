@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (AA_ACT_NONE, AA_ACT_SILU, AA_BF16, AA_F16, AA_F32, AaAttention, AaAttnOperand,
-                   AaConvGemm, AaDpmStep, AaGroupNorm)
+                   AaConvGemm, AaDpmStep, AaDpmStepTok, AaGroupNorm, AaPackLatents)
 
 _DT = {torch.float16: AA_F16, torch.bfloat16: AA_BF16, torch.float32: AA_F32}
 
@@ -485,3 +485,49 @@ def cfg_dpm_step(eps_uncond, eps_text, latents, x0_prev, latents_lp, guidance, s
     d.guidance, d.sigma_s, d.alpha_s, d.c_x, d.c_d0, d.c_d1 = guidance, sigma_s, alpha_s, c_x, c_d0, c_d1
     d.dtype = _DT[eps_uncond.dtype]
     _run(lib.aa_cfg_dpm_step, C.byref(d), _stream(latents))
+
+
+# ------------------------------------------------------------------------------------- step glue
+def timestep_embedding(t: torch.Tensor, dim: int, dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0) of the fp32 DEVICE array `t` [n] -> [n, dim]."""
+    lib = _lib.get()
+    _check(t, out)
+    assert t.dtype == torch.float32 and t.dim() == 1
+    y = torch.empty(t.shape[0], dim, dtype=dtype, device=t.device) if out is None else out
+    _run(lib.aa_timestep_embedding, _ptr(t), _ptr(y), t.shape[0], dim, _DT[y.dtype], _stream(t))
+    return y
+
+
+def pack_latents(sample: torch.Tensor, cond: torch.Tensor, mask: Optional[torch.Tensor], batch: int, dtype,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sample [Bs,C,T,h,w] (fp32 or `dtype`), cond [Bc,C,1,h,w], mask [Bm,1,1,h,w] or None -> tokens [batch*(T+1)*h*w, 8]."""
+    lib = _lib.get()
+    _check(sample, cond, mask, out)
+    bs, c, frames, h, w = sample.shape
+    y = torch.empty(batch * (frames + 1) * h * w, 8, dtype=dtype, device=sample.device) if out is None else out
+    d = AaPackLatents()
+    d.sample, d.cond, d.mask, d.out = _ptr(sample), _ptr(cond), _ptr(mask), _ptr(y)
+    d.batch, d.sample_batch, d.cond_batch = batch, bs, cond.shape[0]
+    d.mask_batch = 0 if mask is None else mask.shape[0]
+    d.channels, d.frames, d.hw = c, frames, h * w
+    d.dtype, d.sample_dtype = _DT[dtype], _DT[sample.dtype]
+    assert cond.dtype == dtype and (mask is None or mask.dtype == dtype)
+    _run(lib.aa_pack_latents, C.byref(d), _stream(sample))
+    return y
+
+
+def cfg_dpm_step_tokens(eps_tokens, latents, x0_prev, latents_lp, guidance, coeffs, next_t=None, next_t_value=0.0):
+    """Fused CFG + DPM-Solver++ update reading the UNet's token-layout output [(2*)clips*(T+1)*hw, eps_ld]."""
+    lib = _lib.get()
+    _check(eps_tokens, latents, x0_prev, latents_lp, next_t)
+    clips, c, frames, h, w = latents.shape
+    d = AaDpmStepTok()
+    d.eps_tokens, d.latents, d.x0_prev, d.latents_lp = _ptr(eps_tokens), _ptr(latents), _ptr(x0_prev), _ptr(latents_lp)
+    d.next_t, d.next_t_count, d.next_t_value = _ptr(next_t), 0 if next_t is None else next_t.numel(), float(next_t_value)
+    d.clips, d.channels, d.frames, d.hw = clips, c, frames, h * w
+    d.eps_ld = eps_tokens.stride(0)
+    d.guidance_on, d.guidance = int(guidance is not None), float(guidance or 0.0)
+    d.sigma_s, d.alpha_s, d.c_x, d.c_d0, d.c_d1 = (coeffs[k] for k in ("sigma_s", "alpha_s", "c_x", "c_d0", "c_d1"))
+    d.dtype = _DT[eps_tokens.dtype]
+    assert latents.dtype == torch.float32 and x0_prev.dtype == torch.float32
+    _run(lib.aa_cfg_dpm_step_tokens, C.byref(d), _stream(latents))

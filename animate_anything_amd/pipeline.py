@@ -137,35 +137,62 @@ class LatentToVideoPipeline:
     def denoise(self, latents, prompt_embeds, condition_latent, mask, motion, timesteps, guidance_scale,
                 callback=None, callback_steps=1):
         """The hot loop (reference pipeline.py:163-198).  `prompt_embeds` already holds [uncond; text]
-        when guidance is on.  Latents are kept in fp32; the UNet sees a storage-dtype copy."""
+        when guidance is on.  Latents are kept in fp32.
+
+        With the DPM-Solver++ scheduler one step is exactly two device submissions: the UNet session (a hipGraph replay
+        holding timestep embedding + input packing + the whole forward when graphs are enabled) and the fused
+        guidance + solver kernel, which reads the UNet's token-layout output, updates the fp32 latents in place - they ARE
+        the session's `sample` input, duplicated for guidance by the packing kernel - and deposits the next timestep."""
+        cfg = guidance_scale > 1.0
+        sched = self.scheduler
+        unet = self.unet
+        if not (isinstance(sched, DPMSolverMultistepScheduler) and hasattr(unet, "session")):
+            return self._denoise_generic(latents, prompt_embeds, condition_latent, mask, motion, timesteps, guidance_scale,
+                                         callback, callback_steps)
+        dev = latents.device
+        b0, _, frames, h, w = latents.shape
+        b = 2 * b0 if cfg else b0
+        use_mask = bool(unet.motion_mask and mask is not None)
+        has_motion = bool(unet.motion_strength and motion is not None)
+        sess = unet.session(b, frames, h, w, tuple(prompt_embeds.shape[1:]), use_mask, has_motion, False, torch.float32, b0,
+                            condition_latent.shape[0], mask.shape[0] if use_mask else 0, dev)
+        mot = None
+        if has_motion:
+            mot = torch.as_tensor(motion, device=dev).to(torch.float32).reshape(-1).expand(b).contiguous()
+        ts = [int(t) for t in timesteps]
+        sess.load(sample=latents, cond=condition_latent, mask=mask if use_mask else None, text=prompt_embeds, motion=mot,
+                  t=torch.full((b,), float(ts[0]) if ts else 0.0, dtype=torch.float32, device=dev))
+        x = sess.inputs["sample"]                               # fp32 [b0,C,T,h,w]: updated in place by the solver kernel
+        x0_prev = torch.zeros_like(x)
+        for i, t in enumerate(ts):
+            eps = sess.run()                                    # tokens [b*(T+1)*h*w, out_channels]
+            k = sched.coefficients(sched.index_for_timestep(t), i > 0)
+            ops.cfg_dpm_step_tokens(eps, x, x0_prev, None, guidance_scale if cfg else None, k,
+                                    next_t=sess.inputs["t"], next_t_value=float(ts[i + 1]) if i + 1 < len(ts) else float(t))
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, x)
+        return x.clone()
+
+    def _denoise_generic(self, latents, prompt_embeds, condition_latent, mask, motion, timesteps, guidance_scale,
+                         callback=None, callback_steps=1):
+        """Any scheduler with a diffusers-style `step()`: the UNet through its module `forward`, guidance and the update as
+        torch expressions (the reference's own sequence, pipeline.py:165-192)."""
         cfg = guidance_scale > 1.0
         dt = self.unet.dtype
         sched = self.scheduler
-        fused = isinstance(sched, DPMSolverMultistepScheduler)
         x = latents.float().contiguous()
-        x_lp = x.to(dt)
-        x0_prev = torch.zeros_like(x)
         cond = torch.cat([condition_latent, condition_latent]) if cfg else condition_latent     # :160-161
-        have_prev = False
         for i, t in enumerate(timesteps):
+            x_lp = x.to(dt)
             model_in = torch.cat([x_lp, x_lp]) if cfg else x_lp                                  # :165
             eps = self.unet(model_in, t, encoder_hidden_states=prompt_embeds, condition_latent=cond, mask=mask,
                             motion=None if motion is None else torch.as_tensor(motion, device=x.device)).sample
-            eps = eps.contiguous()
             e_u, e_t = (eps[: x.shape[0]], eps[x.shape[0]:]) if cfg else (eps, eps)
-            if fused:
-                k = sched.coefficients(sched.index_for_timestep(t), have_prev)
-                # [B,C,T,h,w] is elementwise-consistent between eps, x and x0_prev: no reshapes needed
-                ops.cfg_dpm_step(e_u, e_t, x, x0_prev, x_lp, guidance_scale if cfg else 0.0,
-                                 k["sigma_s"], k["alpha_s"], k["c_x"], k["c_d0"], k["c_d1"])
-                have_prev = True
-            else:
-                e = e_u.float() + guidance_scale * (e_t.float() - e_u.float()) if cfg else eps.float()
-                b, c, f, h, w = x.shape
-                flat = sched.step(e.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w), t,
-                                  x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)).prev_sample
-                x = flat.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4).contiguous()
-                x_lp = x.to(dt)
+            e = e_u.float() + guidance_scale * (e_t.float() - e_u.float()) if cfg else eps.float()
+            b, c, f, h, w = x.shape
+            flat = sched.step(e.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w), t,
+                              x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)).prev_sample
+            x = flat.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4).contiguous()
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, x)
         return x

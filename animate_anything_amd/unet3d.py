@@ -10,7 +10,6 @@ current stream, so it can be captured in a hipGraph (`enable_graph`).
 from __future__ import annotations
 
 import json
-import math
 import os
 from dataclasses import dataclass
 from types import SimpleNamespace
@@ -28,14 +27,6 @@ from .layers import (Conv2d, Downsample2D, Grid, GroupNorm, Linear, ResnetBlock2
 class UNet3DConditionOutput:
     """reference unet_3d_condition_mask.py:43-51."""
     sample: torch.Tensor
-
-
-def timestep_sinusoid(t: torch.Tensor, dim: int) -> torch.Tensor:
-    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): fp32 [len(t), dim]."""
-    half = dim // 2
-    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
-    arg = t.reshape(-1).float()[:, None] * freq[None, :]
-    return torch.cat([arg.cos(), arg.sin()], dim=-1)
 
 
 class _Stage(nn.Module):
@@ -339,13 +330,19 @@ class UNet3DConditionModel(nn.Module):
                   os.path.join(path, "diffusion_pytorch_model.safetensors"))
 
     # ------------------------------------------------------------------ hot path
-    def _core(self, x8, t_sin, cond_sin, text_tokens, g: Grid, text_len: int, use_mask: bool, upsample_sizes):
+    def _core(self, sample, cond, mask, t, motion_t, cond_emb, text_tokens, g: Grid, text_len: int, upsample_sizes):
         """Everything between the boundary tensors: only libaa_mi355 launches (graph-capturable).
-        x8: [tokens, 8] input latents (+mask) zero-padded to 8 channels; returns [tokens, out_channels]."""
+        sample [Bs,C,T,h,w] (fp32 or storage dtype), cond [Bc,C,1,h,w], mask [Bm,1,1,h,w] | None, t fp32 [B], motion_t fp32 [B] |
+        None (or a ready [B, ch0] `cond_emb`), text_tokens [B*L, D]; returns [B*(T+1)*h*w, out_channels] tokens."""
+        dt = text_tokens.dtype
+        ch0 = self.conv_in.out_channels
+        t_sin = ops.timestep_embedding(t, ch0, dt)                                       # :408-413
+        cond_sin = ops.timestep_embedding(motion_t, ch0, dt) if motion_t is not None else cond_emb   # :414-416
+        x8 = ops.pack_latents(sample, cond, mask, g.clips, dt)                            # :376, :424-428
         temb_silu = self.time_embedding.tokens(t_sin, cond_sin, final_silu=True)       # [clips, 4*ch0]
         self._project_time_embeddings(temb_silu)
         self._project_text(text_tokens)
-        conv_in = self.conv_in2 if use_mask else self.conv_in
+        conv_in = self.conv_in2 if mask is not None else self.conv_in
         x = conv_in.tokens(x8, ops.conv3x3_geom(g.images, g.h, g.w))
         if g.frames > 1:
             x = self.transformer_in.tokens(x, g)
@@ -370,84 +367,99 @@ class UNet3DConditionModel(nn.Module):
         if not sample.is_cuda and not _lib.host_pointers_ok():
             raise RuntimeError("animate_anything_amd.UNet3DConditionModel runs on the GPU only (no CPU fallback)")
         dt, dev = self.dtype, sample.device
-        sample = torch.cat([condition_latent.to(dt), sample.to(dt)], dim=2)            # :376
         b, _, frames, h, w = sample.shape
-        up_factor = 2 ** self.num_upsamplers
-        forward_upsample = (h % up_factor != 0) or (w % up_factor != 0)               # :381
-
         t = timestep
         if not torch.is_tensor(t):
-            t = torch.tensor([t], dtype=torch.float64 if isinstance(t, float) else torch.int64, device=dev)
-        elif t.dim() == 0:
-            t = t[None]
-        t = t.to(dev).expand(b)
-        ch0 = self.conv_in.out_channels
-        t_sin = timestep_sinusoid(t, ch0).to(dt)                                        # :408-413
-        cond_sin = None
+            t = torch.tensor([float(t)], dtype=torch.float32, device=dev)
+        t = t.to(device=dev, dtype=torch.float32).reshape(-1).expand(b).contiguous()
+        motion_t = cond_emb = None
         if self.motion_strength and motion is not None:                                 # :414-416
-            m = torch.as_tensor(motion, device=dev)
-            cond_sin = timestep_sinusoid(m, ch0).to(dt).expand(b, ch0).contiguous()
+            motion_t = torch.as_tensor(motion, device=dev).to(torch.float32).reshape(-1).expand(b).contiguous()
         elif timestep_cond is not None:
-            cond_sin = timestep_cond.to(dt).expand(b, ch0).contiguous()
-
+            cond_emb = timestep_cond.to(dt).expand(b, self.conv_in.out_channels).contiguous()
         use_mask = bool(self.motion_mask and mask is not None)
-        if use_mask:                                                                    # :424-428
-            mm = mask.to(dt).repeat(b // mask.shape[0], 1, frames, 1, 1)
-            sample = torch.cat([mm, sample], dim=1)
-        cin = sample.shape[1]
-        x8 = torch.zeros(b, frames, h, w, 8, dtype=dt, device=dev)
-        x8[..., :cin] = sample.permute(0, 2, 3, 4, 1)
-        x8 = x8.reshape(-1, 8)
-
-        text = encoder_hidden_states.to(dt)
-        text_len = text.shape[1]
-        text_tokens = text.reshape(-1, text.shape[-1]).contiguous()
-        g = Grid(b, frames, h, w)
-
-        # sizes the up path must hit when H or W is not a multiple of 2**num_upsamplers (:490-491)
-        sizes = [(h, w)]
-        for _ in range(self.num_upsamplers):
-            ph, pw = sizes[-1]
-            sizes.append(((ph - 1) // 2 + 1, (pw - 1) // 2 + 1))
-        upsample_sizes = [None] * len(self.up_blocks)
-        if forward_upsample:
-            for i in range(self.num_upsamplers):
-                upsample_sizes[i] = sizes[self.num_upsamplers - 1 - i]
-
-        y = self._run_core(x8, t_sin.contiguous(), cond_sin, text_tokens, g, text_len, use_mask, tuple(upsample_sizes))
-        y = y.reshape(b, frames, h, w, -1).permute(0, 4, 1, 2, 3)[:, :, 1:]            # :521-522
+        if sample.dtype not in (torch.float32, dt):
+            sample = sample.to(dt)
+        sess = self.session(b, frames, h, w, tuple(encoder_hidden_states.shape[1:]), use_mask, motion_t is not None,
+                            cond_emb is not None, sample.dtype, sample.shape[0], condition_latent.shape[0],
+                            mask.shape[0] if use_mask else 0, dev)
+        sess.load(sample=sample, cond=condition_latent, mask=mask if use_mask else None, t=t, motion=motion_t,
+                  cond_emb=cond_emb, text=encoder_hidden_states)
+        y = sess.run()
+        y = y.reshape(b, frames + 1, h, w, -1).permute(0, 4, 1, 2, 3)[:, :, 1:]       # :521-522
         return UNet3DConditionOutput(sample=y) if return_dict else (y,)
 
-    # ------------------------------------------------------------------ hipGraph replay
+    # ------------------------------------------------------------------ sessions: static inputs (+ hipGraph replay)
     def enable_graph(self, enabled=True):
-        """Capture `_core` in a hipGraph on first use per input signature and replay it afterwards
-        (removes ~1k host launches per denoising step)."""
+        """Capture the forward (timestep embedding + input packing + `_core`) in a hipGraph on first use per input
+        signature and replay it afterwards (removes ~1k host launches per denoising step)."""
         self._graph = {} if enabled else None
 
-    def _run_core(self, x8, t_sin, cond_sin, text_tokens, g, text_len, use_mask, upsample_sizes):
-        if self._graph is None:
-            return self._core(x8, t_sin, cond_sin, text_tokens, g, text_len, use_mask, upsample_sizes)
-        key = (tuple(x8.shape), tuple(text_tokens.shape), g, text_len, use_mask, upsample_sizes, cond_sin is None,
-               x8.dtype)
-        ent = self._graph.get(key)
-        if ent is None:
-            static = dict(x8=x8.clone(), t=t_sin.clone(), c=None if cond_sin is None else cond_sin.clone(),
-                          text=text_tokens.clone())
+    def session(self, batch, frames, h, w, text_shape, use_mask, has_motion, has_cond_emb, sample_dtype, sample_batch,
+                cond_batch, mask_batch, device):
+        """The static input buffers (and, when graphs are enabled, the captured hipGraph) of one input signature.
+        A caller that owns the denoising loop (LatentToVideoPipeline.denoise) writes its inputs straight into
+        `sess.inputs[...]` once and then only calls `sess.run()` per step."""
+        key = (batch, frames, h, w, tuple(text_shape), use_mask, has_motion, has_cond_emb, sample_dtype, sample_batch,
+               cond_batch, mask_batch, self.dtype, str(device))
+        store = self._graph if self._graph is not None else self.__dict__.setdefault("_eager_sessions", {})
+        sess = store.get(key)
+        if sess is None:
+            if self._graph is None:
+                store.clear()                                  # eager sessions hold only input buffers: keep one
+            sess = store[key] = _Session(self, key, device)
+        return sess
+
+
+class _Session:
+    def __init__(self, net, key, device):
+        (b, frames, h, w, text_shape, use_mask, has_motion, has_cond_emb, sample_dtype, sample_batch, cond_batch, mask_batch,
+         dt, _dev) = key
+        self.net, self.b, self.frames, self.h, self.w = net, b, frames, h, w
+        z = lambda *s, dtype=dt: torch.zeros(*s, dtype=dtype, device=device)
+        c = net.config.in_channels
+        self.inputs = dict(sample=z(sample_batch, c, frames, h, w, dtype=sample_dtype), cond=z(cond_batch, c, 1, h, w),
+                           mask=z(mask_batch, 1, 1, h, w) if use_mask else None, t=z(b, dtype=torch.float32),
+                           motion=z(b, dtype=torch.float32) if has_motion else None,
+                           cond_emb=z(b, net.conv_in.out_channels) if has_cond_emb else None, text=z(b, *text_shape))
+        self.text_len = text_shape[0]
+        self.grid = Grid(b, frames + 1, h, w)
+        # sizes the up path must hit when H or W is not a multiple of 2**num_upsamplers (:381-383, :490-491)
+        up_factor = 2 ** net.num_upsamplers
+        sizes = [(h, w)]
+        for _ in range(net.num_upsamplers):
+            ph, pw = sizes[-1]
+            sizes.append(((ph - 1) // 2 + 1, (pw - 1) // 2 + 1))
+        ups = [None] * len(net.up_blocks)
+        if (h % up_factor != 0) or (w % up_factor != 0):
+            for i in range(net.num_upsamplers):
+                ups[i] = sizes[net.num_upsamplers - 1 - i]
+        self.upsample_sizes = tuple(ups)
+        self.graph = None
+        self.out = None
+
+    def load(self, **tensors):
+        for k, v in tensors.items():
+            dst = self.inputs[k]
+            if dst is not None and v is not None and dst.data_ptr() != v.data_ptr():
+                dst.copy_(v.reshape(dst.shape) if v.numel() == dst.numel() else v.expand(dst.shape))
+
+    def _core(self):
+        i = self.inputs
+        return self.net._core(i["sample"], i["cond"], i["mask"], i["t"], i["motion"], i["cond_emb"],
+                              i["text"].reshape(-1, i["text"].shape[-1]), self.grid, self.text_len, self.upsample_sizes)
+
+    def run(self):
+        if self.net._graph is None:
+            return self._core()
+        if self.graph is None:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):                                   # warm-up outside capture (packs weights)
-                self._core(static["x8"], static["t"], static["c"], static["text"], g, text_len, use_mask, upsample_sizes)
+            with torch.cuda.stream(s):                                   # warm-up outside capture (packs weights, autotunes)
+                self._core()
             torch.cuda.current_stream().wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self._core(static["x8"], static["t"], static["c"], static["text"], g, text_len, use_mask,
-                                 upsample_sizes)
-            ent = self._graph[key] = (graph, static, out)
-        graph, static, out = ent
-        static["x8"].copy_(x8)
-        static["t"].copy_(t_sin)
-        if cond_sin is not None:
-            static["c"].copy_(cond_sin)
-        static["text"].copy_(text_tokens)
-        graph.replay()
-        return out
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._core()
+        self.graph.replay()
+        return self.out

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AA_VERSION 100
+#define AA_VERSION 101
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
@@ -194,6 +194,61 @@ typedef struct AaDpmStep {
 } AaDpmStep;
 
 int aa_cfg_dpm_step(const AaDpmStep* d, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Step glue (version 101): with these three the whole denoising step is library launches only -
+ * [timestep embedding + input packing + UNet] captured in one hipGraph, then the guidance / solver update.
+ *
+ * aa_timestep_embedding: diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)
+ * (reference unet_3d_condition_mask.py:408-416): out[r, :] = [cos(t[r]*f_k) | sin(t[r]*f_k)],
+ * f_k = exp(-ln(10000) * k / (dim/2)); `t` is a DEVICE array of n fp32 values (so a captured graph can
+ * be replayed with a new timestep), out is [n][dim] storage dtype.
+ * ---------------------------------------------------------------------------------------------- */
+int aa_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim, int32_t dtype, void* stream);
+
+/* aa_pack_latents: the UNet's input assembly (reference unet_3d_condition_mask.py:376,424-428):
+ * sample [sample_batch][channels][frames][hw] (fp32 or storage dtype) gets the condition latent
+ * [cond_batch][channels][1][hw] prepended as frame 0 and, when `mask` is given, the mask
+ * [mask_batch][1][1][hw] prepended as channel 0 of every frame; the result is written as the channels-last
+ * token matrix [batch][frames+1][hw][8] (zero padded to 8 channels) that conv_in / conv_in2 read.
+ * Batch element b reads sample b % sample_batch, cond b % cond_batch, mask b % mask_batch (classifier-free
+ * guidance runs the same latents twice: models/pipeline.py:165). */
+typedef struct AaPackLatents {
+    const void* sample;
+    const void* cond;
+    const void* mask;      /* NULL: no mask channel */
+    void* out;             /* [batch*(frames+1)*hw][8] storage dtype */
+    int32_t batch, sample_batch, cond_batch, mask_batch;
+    int32_t channels;      /* latent channels (4); channels + (mask ? 1 : 0) <= 8 */
+    int32_t frames;        /* frames of `sample` (the output has frames + 1) */
+    int32_t hw;
+    int32_t dtype;         /* storage dtype of cond / mask / out */
+    int32_t sample_dtype;  /* AA_F32 or == dtype */
+} AaPackLatents;
+
+int aa_pack_latents(const AaPackLatents* d, void* stream);
+
+/* aa_cfg_dpm_step_tokens: aa_cfg_dpm_step reading the UNet output where the UNet left it - the token matrix
+ * [2*clips or clips][frames+1][hw][eps_ld] with frame 0 (the condition frame) skipped (reference
+ * unet_3d_condition_mask.py:522) and, under guidance, the unconditional clips first (models/pipeline.py:165,181-183).
+ * Updates the fp32 latents / x0_prev [clips][channels][frames][hw] in place, optionally writes their storage-dtype
+ * copy (the next UNet `sample`) and the next timestep value(s) for aa_timestep_embedding. */
+typedef struct AaDpmStepTok {
+    const void* eps_tokens;
+    void* latents;            /* fp32, updated in place */
+    void* x0_prev;            /* fp32, updated in place */
+    void* latents_lp;         /* storage dtype copy of the new latents, may be NULL */
+    float* next_t;            /* device array receiving `next_t_value` (next_t_count <= 256 entries), may be NULL */
+    int32_t next_t_count;
+    float next_t_value;
+    int32_t clips, channels, frames, hw;
+    int32_t eps_ld;           /* row pitch of the token matrix in elements (>= channels) */
+    int32_t guidance_on;
+    float guidance, sigma_s, alpha_s, c_x, c_d0, c_d1;
+    int32_t dtype;
+} AaDpmStepTok;
+
+int aa_cfg_dpm_step_tokens(const AaDpmStepTok* d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -425,3 +425,54 @@ def test_split_k_long_k_few_tiles(backend):
     temb = rnd(n, cout, seed=88)
     y = ops.conv_gemm(nhwc(xi), ops.pack_weight(wt, bb), ops.conv3x3_geom(n, h, w_), rowvec=temb, rowvec_div=h * w_)
     close(y, nhwc(F.conv2d(xi.float(), wt.float(), bb.float(), padding=1) + temb.float()[:, :, None, None]))
+
+
+# ---- step glue (aa_timestep_embedding, aa_pack_latents, aa_cfg_dpm_step_tokens) ----
+def test_timestep_embedding(backend):
+    t = torch.tensor([951.0, 3.0, 0.0, 501.5], dtype=torch.float32, device=DEV)
+    y = ops.timestep_embedding(t, 320, DT)
+    half = 160
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    arg = t.cpu()[:, None] * freq[None, :]
+    close(y, torch.cat([arg.cos(), arg.sin()], dim=-1), tol=2e-3)
+
+
+@pytest.mark.parametrize("with_mask,sample_f32", [(True, True), (False, False)])
+def test_pack_latents(backend, with_mask, sample_f32):
+    """cat([cond, sample], dim=2) -> cat([mask, .], dim=1) -> channels-last tokens padded to 8 channels, CFG duplication
+    (reference unet_3d_condition_mask.py:376,424-428; models/pipeline.py:165)."""
+    bs, b, c, frames, h, w = 1, 2, 4, 3, 3, 5
+    g = torch.Generator().manual_seed(151)
+    sample = torch.randn(bs, c, frames, h, w, generator=g).to(torch.float32 if sample_f32 else DT).to(DEV)
+    cond = rnd(bs, c, 1, h, w, seed=152)
+    mask = (torch.rand(1, 1, 1, h, w, generator=g) > 0.5).to(DT).to(DEV) if with_mask else None
+    y = ops.pack_latents(sample, cond, mask, b, DT)
+    full = torch.cat([cond.float().cpu(), sample.float().cpu()], dim=2).repeat(b // bs, 1, 1, 1, 1)
+    if with_mask:
+        full = torch.cat([mask.float().cpu().repeat(b, 1, frames + 1, 1, 1), full], dim=1)
+    ref = torch.zeros(b, frames + 1, h, w, 8)
+    ref[..., :full.shape[1]] = full.permute(0, 2, 3, 4, 1)
+    assert torch.equal(y.float().cpu(), ref.reshape(-1, 8).to(DT).float())
+
+
+@pytest.mark.parametrize("cfg", [True, False])
+def test_cfg_dpm_step_tokens(backend, cfg):
+    """Guidance + DPM-Solver++ update fed from the UNet's token layout: frame 0 skipped, [uncond clips | text clips]."""
+    clips, c, frames, h, w, ld = 2, 4, 3, 2, 5, 4
+    b = 2 * clips if cfg else clips
+    g = torch.Generator().manual_seed(161)
+    eps_tok = rnd(b * (frames + 1) * h * w, ld, seed=162)
+    x = torch.randn(clips, c, frames, h, w, generator=g).to(DEV)
+    x0p = torch.randn(clips, c, frames, h, w, generator=g).to(DEV)
+    lp = torch.empty(clips, c, frames, h, w, dtype=DT, device=DEV)
+    nt = torch.zeros(b, dtype=torch.float32, device=DEV)
+    xr, x0r = x.clone().cpu(), x0p.clone().cpu()
+    k = dict(sigma_s=0.7, alpha_s=0.71, c_x=0.9, c_d0=-0.2, c_d1=-0.05)
+    ops.cfg_dpm_step_tokens(eps_tok, x, x0p, lp, 9.0 if cfg else None, k, next_t=nt, next_t_value=913.0)
+    e = eps_tok.float().cpu().reshape(b, frames + 1, h, w, ld).permute(0, 4, 1, 2, 3)[:, :c, 1:]
+    eps = e[:clips] + 9.0 * (e[clips:] - e[:clips]) if cfg else e
+    x0 = (xr - 0.7 * eps) / 0.71
+    close(x, 0.9 * xr + 0.2 * x0 + 0.05 * (x0 - x0r), tol=1e-5)
+    close(x0p, x0, tol=1e-5)
+    close(lp, x, tol=2e-3)
+    assert torch.equal(nt.cpu(), torch.full((b,), 913.0))
