@@ -69,7 +69,16 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_stats_kernel(const AaGro
 #pragma unroll
             for (int e = 0; e < 8; ++e) kp[e] = gn_pivot<T>(x0, x1, p.c0, p.c1, base, ((slot * 8 + e) / cg) * cg);
             int t = t_begin + roff;
-            for (; t + rows_per_pass < t_end; t += 2 * rows_per_pass) {      // two independent rows in flight
+            for (; t + 3 * rows_per_pass < t_end; t += 4 * rows_per_pass) {  // four independent rows in flight per thread
+                Pack8<T> v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u].raw = load8<T>(x0, x1, p.c0, p.c1, base + t + u * rows_per_pass, slot * 8);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float f = (float)v[u].e[e] - kp[e]; a[e] += f; b[e] += f * f; }
+            }
+            for (; t + rows_per_pass < t_end; t += 2 * rows_per_pass) {
                 Pack8<T> v, w;
                 v.raw = load8<T>(x0, x1, p.c0, p.c1, base + t, slot * 8);
                 w.raw = load8<T>(x0, x1, p.c0, p.c1, base + t + rows_per_pass, slot * 8);
@@ -189,6 +198,13 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_apply_kernel(const AaGro
             return o;
         };
         int t = t_begin + roff;
+        for (; t + 3 * rows_per_pass < t_end; t += 4 * rows_per_pass) {          // four independent rows in flight per thread
+            Pack8<T> v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u].raw = load8<T>(x0, x1, p.c0, p.c1, base + t + u * rows_per_pass, slot * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<u32x4*>(y + (base + t + u * rows_per_pass) * C + slot * 8) = norm8(v[u]).raw;
+        }
         for (; t + rows_per_pass < t_end; t += 2 * rows_per_pass) {
             Pack8<T> va, vb;
             va.raw = load8<T>(x0, x1, p.c0, p.c1, base + t, slot * 8);
