@@ -159,7 +159,8 @@ def eval(pipeline, validation_data, out_file, index, forward_t=25, preview=True,
 
 
 def batch_eval(unet, text_encoder, vae, tokenizer, scheduler_config, validation_data, output_dir, preview,
-               global_step=0, iters=6, generator=None, indices=None, seed=None):
+               global_step=0, iters=6, generator=None, indices=None, seed=None, lora_path=None, lora_rank=16,
+               unet_lora_modules=("UNet3DConditionModel",)):
     """train.py:793-823: pipeline with DPM-Solver++ built from the checkpoint's scheduler config, `iters` samples.
     `indices` (clip sharding, main_eval): render only these sample indices, each with its own generator seeded
     `seed + index` (distributed.clip_seed) so that a sample does not depend on which rank renders it."""
@@ -167,6 +168,10 @@ def batch_eval(unet, text_encoder, vae, tokenizer, scheduler_config, validation_
     scheduler = DPMSolverMultistepScheduler.from_config(scheduler_config)
     pipeline = LatentToVideoPipeline(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, unet=unet,
                                      scheduler=scheduler)
+    if lora_path:                                         # train_lora.py:909-917: adapters for inference (folded, not wrapped)
+        from .lora import inject_inferable_lora
+        inject_inferable_lora(pipeline, lora_path, r=lora_rank, unet_replace_modules=unet_lora_modules)
+        print(f"LoRA injected to {list(unet_lora_modules)}, lora path: {lora_path}")
     scheduler.set_timesteps(validation_data.num_inference_steps, device=vae.device)
     results = []
     from .distributed import clip_seed
@@ -183,7 +188,8 @@ def batch_eval(unet, text_encoder, vae, tokenizer, scheduler_config, validation_
 
 
 def main_eval(pretrained_model_path, validation_data, seed=None, motion_mask=None, motion_strength=None,
-              output_dir="output/demo", iters=6, dtype="fp16", graph=True, **kwargs):
+              output_dir="output/demo", iters=6, dtype="fp16", graph=True, lora_path=None, lora_rank=16,
+              unet_lora_modules=("UNet3DConditionModel",), **kwargs):
     """train.py:825-857.  Weights are cast to half precision on the GPU ("cuda" is the HIP device on ROCm).
     The reference accepts `motion_mask` / `motion_strength` here and never forwards them to the UNet constructor
     (train.py:838: the checkpoint's config.json governs); so do we - they are passed on only when the YAML sets them.
@@ -208,10 +214,11 @@ def main_eval(pretrained_model_path, validation_data, seed=None, motion_mask=Non
         unet.enable_graph()
     if world == 1:
         return batch_eval(unet, text_encoder, vae, tokenizer, scfg, validation_data, output_dir, True, iters=iters,
-                          generator=generator)
+                          generator=generator, lora_path=lora_path, lora_rank=lora_rank, unet_lora_modules=unet_lora_modules)
     mine = D.clip_indices(iters, rank, world)
     results = batch_eval(unet, text_encoder, vae, tokenizer, scfg, validation_data, output_dir, True, iters=iters,
-                         generator=generator, indices=mine, seed=seed)
+                         generator=generator, indices=mine, seed=seed, lora_path=lora_path, lora_rank=lora_rank,
+                         unet_lora_modules=unet_lora_modules)
     local = torch.stack([r[2][0] for r in results]) if results else None
     shape = [0] * 5
     if local is not None:
