@@ -290,6 +290,11 @@ static int gn_chunks(const AaGroupNorm& d) {
 template <typename T>
 static int attention_t(const AaAttention& d, void* stream) {
     const int nseq = d.n_outer * d.n_inner;
+    if (d.head_dim == 8) {
+        const dim3 grid((d.q_len + 255) / 256, d.heads, nseq);
+        AA_LAUNCH((attention_d8_kernel<T>), grid, dim3(256), 2 * 256 * 8 * sizeof(T), stream, d);
+        return finish("attention");
+    }
     if (d.q_len > 64) {
         const dim3 grid((d.q_len + 127) / 128, d.heads, nseq);
         AA_LAUNCH((attention_kernel<T, 4>), grid, dim3(256), attn_lds_bytes(d.kv_len), stream, d);
@@ -381,7 +386,7 @@ int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y, in
 int aa_attention(const AaAttention* d, void* stream) {
     using namespace aa;
     if (!d) return fail(AA_E_SHAPE, "attention: null descriptor");
-    if (d->head_dim != 64) return fail(AA_E_SHAPE, "attention: head_dim must be 64 (got %d)", d->head_dim);
+    if (d->head_dim != 64 && d->head_dim != 8) return fail(AA_E_SHAPE, "attention: head_dim must be 64 or 8 (got %d)", d->head_dim);
     if (d->q_len <= 0 || d->kv_len <= 0 || d->heads <= 0 || d->n_outer <= 0 || d->n_inner <= 0) return fail(AA_E_SHAPE, "attention: bad lengths");
     const AaAttnOperand* ops[4] = {&d->q, &d->k, &d->v, &d->o};
     for (const AaAttnOperand* x : ops) {
@@ -389,8 +394,8 @@ int aa_attention(const AaAttention* d, void* stream) {
         if (x->outer_div <= 0) return fail(AA_E_SHAPE, "attention: outer_div must be >= 1");
     }
     // K / V are read through buffer descriptors with 32-bit byte offsets; offsets >= 2^31 mean "zero"
-    if (attn_extent_bytes(d->k, d->n_outer, d->n_inner, d->kv_len) >= ((int64_t)1 << 31) ||
-        attn_extent_bytes(d->v, d->n_outer, d->n_inner, d->kv_len) >= ((int64_t)1 << 31))
+    if (d->head_dim == 64 && (attn_extent_bytes(d->k, d->n_outer, d->n_inner, d->kv_len) >= ((int64_t)1 << 31) ||
+        attn_extent_bytes(d->v, d->n_outer, d->n_inner, d->kv_len) >= ((int64_t)1 << 31)))
         return fail(AA_E_SHAPE, "attention: K / V operand must stay below 2 GiB");
     if (d->dtype == AA_F16) return attention_t<f16_t>(*d, stream);
     if (d->dtype == AA_BF16) return attention_t<bf16_t>(*d, stream);

@@ -443,22 +443,22 @@ def _operand(t: torch.Tensor, col0: int, outer_stride: int, inner_stride: int, p
 
 def attention(q: torch.Tensor, q_col0: int, k: torch.Tensor, k_col0: int, v: torch.Tensor, v_col0: int,
               heads: int, n_outer: int, n_inner: int, q_len: int, kv_len: int,
-              q_strides, kv_strides, kv_outer_div: int = 1, scale: Optional[float] = None) -> torch.Tensor:
+              q_strides, kv_strides, kv_outer_div: int = 1, scale: Optional[float] = None, head_dim: int = 64) -> torch.Tensor:
     """softmax(q k^T * scale) v for every (outer, inner, head).  `*_strides` = (outer, inner, pos)
     row strides of the token matrices; output rows use the q addressing, columns [0, heads*64)."""
     lib = _lib.get()
     for t in (q, k, v):                                   # operands may be column slices of wider matrices (ld = stride(0))
         if (not t.is_cuda and not _lib.host_pointers_ok()) or t.stride(-1) != 1:
             raise RuntimeError("attention: operands must be GPU tensors with contiguous rows")
-    out = torch.empty(q.shape[0], heads * 64, dtype=q.dtype, device=q.device)
+    out = torch.empty(q.shape[0], heads * head_dim, dtype=q.dtype, device=q.device)
     d = AaAttention()
     d.q = _operand(q, q_col0, *q_strides)
     d.k = _operand(k, k_col0, *kv_strides, outer_div=kv_outer_div)
     d.v = _operand(v, v_col0, *kv_strides, outer_div=kv_outer_div)
     d.o = _operand(out, 0, *q_strides)
-    d.n_outer, d.n_inner, d.heads, d.head_dim = n_outer, n_inner, heads, 64
+    d.n_outer, d.n_inner, d.heads, d.head_dim = n_outer, n_inner, heads, head_dim
     d.q_len, d.kv_len, d.dtype = q_len, kv_len, _DT[q.dtype]
-    d.scale = 0.125 if scale is None else scale
+    d.scale = float(head_dim) ** -0.5 if scale is None else scale
     _run(lib.aa_attention, C.byref(d), _stream(q))
     return out
 

@@ -142,8 +142,9 @@ int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y,
                  int64_t rows, int32_t channels, float eps, int32_t dtype, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
- * aa_attention: O = softmax(Q K^T * scale) V per (sequence, head), head_dim 64, flash-style
- * (scores never leave the chip).  Replaces F.scaled_dot_product_attention as selected by the
+ * aa_attention: O = softmax(Q K^T * scale) V per (sequence, head), head_dim 64 (matrix cores) or 8 (vector
+ * ALUs: the 32-head x 8-channel attention of the layerdiffuse alpha decoder, reference
+ * models/layerdiffuse_VAE.py:58), flash-style (scores never leave the chip).  Replaces F.scaled_dot_product_attention as selected by the
  * reference's AttnProcessor2_0 (train.py:124-138).
  * A sequence is addressed as (outer o, inner i); the row of position p in operand X is
  *     (o / X.outer_div) * X.outer_stride + i * X.inner_stride + p * X.pos_stride      [tokens]

@@ -476,3 +476,15 @@ def test_cfg_dpm_step_tokens(backend, cfg):
     close(x0p, x0, tol=1e-5)
     close(lp, x, tol=2e-3)
     assert torch.equal(nt.cpu(), torch.full((b,), 913.0))
+
+
+@pytest.mark.parametrize("L", [100, 300])
+def test_attention_head_dim_8(backend, L):
+    """32 heads x 8 channels (layerdiffuse UNet384 attention), several 256-key tiles, ragged tail."""
+    n, heads = 2, 4
+    C = heads * 8
+    qkv = rnd(n * L, 3 * C, scale=1.5, seed=171)
+    o = ops.attention(qkv, 0, qkv, C, qkv, 2 * C, heads, n, 1, L, L, (L, 0, 1), (L, 0, 1), head_dim=8)
+    x = qkv.reshape(n, L, 3, heads, 8).permute(2, 0, 3, 1, 4)
+    ref = sdpa(x[0], x[1], x[2]).permute(0, 2, 1, 3).reshape(n * L, C)
+    close(o, ref, tol=1e-2)
