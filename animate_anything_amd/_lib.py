@@ -81,7 +81,7 @@ class AaDpmStepTok(C.Structure):
     ]
 
 
-SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_groupnorm_workspace", "aa_groupnorm",
+SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_groupnorm_workspace", "aa_groupnorm",
            "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step",
            "aa_timestep_embedding", "aa_pack_latents", "aa_cfg_dpm_step_tokens")
 
@@ -103,6 +103,8 @@ def bind(path: str) -> C.CDLL:
     lib.aa_set_tile_override.restype = None
     lib.aa_conv_gemm_tile_info.argtypes = [C.c_int, C.POINTER(C.c_int32)]
     lib.aa_conv_gemm_tile_info.restype = C.c_int
+    lib.aa_conv_gemm_tile_ok.argtypes = [C.POINTER(AaConvGemm), C.c_int]
+    lib.aa_conv_gemm_tile_ok.restype = C.c_int
     lib.aa_conv_gemm.argtypes = [C.POINTER(AaConvGemm), C.c_void_p]
     lib.aa_conv_gemm_workspace.argtypes = [C.POINTER(AaConvGemm)]
     lib.aa_conv_gemm_workspace.restype = C.c_size_t
@@ -117,7 +119,7 @@ def bind(path: str) -> C.CDLL:
     lib.aa_timestep_embedding.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.aa_pack_latents.argtypes = [C.POINTER(AaPackLatents), C.c_void_p]
     lib.aa_cfg_dpm_step_tokens.argtypes = [C.POINTER(AaDpmStepTok), C.c_void_p]
-    for s in SYMBOLS[4:]:
+    for s in SYMBOLS[5:]:
         if s not in ("aa_groupnorm_workspace", "aa_conv_gemm_workspace"):
             getattr(lib, s).restype = C.c_int
     return lib

@@ -10,6 +10,7 @@
 #include "aa_mi355.h"
 #include "kernels/conv_gemm.h"
 #include "kernels/conv_gemm_dma.h"
+#include "kernels/conv_slab.h"
 #include "kernels/norm.h"
 #include "kernels/attention.h"
 #include "kernels/glue.h"
@@ -37,7 +38,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tile configurations of the LDS-DMA contraction kernel.  `rate` is the relative throughput of a tile
 // shape once the CUs are full (measured: the L2 -> LDS stream limits the narrow tiles); the chooser
 // minimises rounds(tiles / resident slots) * tile work / rate over the shapes that divide the packed width.
-struct CgCfg { int bm, bn, wm, wn, bk, stages, per_cu; float rate; };
+struct CgCfg { int bm, bn, wm, wn, bk, stages, per_cu; float rate; int slab = 0; };   // slab: conv_slab.h (3x3 stride-1 halo-slab kernel)
 static const CgCfg kCgCfgs[] = {
     {128, 64, 2, 2, 64, 2, 3, 0.78f},     // 0
     {128, 128, 2, 2, 64, 2, 2, 0.90f},    // 1
@@ -74,6 +75,9 @@ static const CgCfg kCgCfgs[] = {
     {128, 128, 2, 2, 64, 2, 2, 0.90f},    // 31 spread
     {192, 320, 3, 2, 64, 2, 1, 1.05f},    // 32 spread
     {128, 256, 2, 2, 32, 2, 2, 1.05f},    // 33 spread
+    // halo-slab 3x3 kernel (conv_slab.h): the activations of a 32-channel unit are staged once for all nine taps
+    {256, 320, 4, 2, 32, 3, 1, 1.00f, 1}, // 34
+    {256, 256, 4, 2, 32, 3, 1, 1.00f, 1}, // 35
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -81,6 +85,14 @@ static thread_local int g_tile_override = -2;   // per calling thread.  -2: read
 static int cg_force_cfg() {
     if (g_tile_override == -2) { const char* e = getenv("AA_FORCE_CFG"); g_tile_override = e ? atoi(e) : -1; }
     return g_tile_override;
+}
+
+// The halo-slab kernel handles 3x3 / stride 1 / pad 1 convolutions whose tiles are whole image rows of one image.
+static bool cg_slab_ok(const AaConvGemm& d, const CgCfg& c) {
+    const int hw = d.h_in * d.w_in;
+    return d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad_h == 1 && d.pad_w == 1 && d.h_virt == d.h_in && d.w_virt == d.w_in &&
+           d.h_out == d.h_in && d.w_out == d.w_in && d.k_order == 1 && d.c0 % 64 == 0 && d.c1 % 64 == 0 && !d.geglu && !d.bias_per_row &&
+           c.bm % d.w_in == 0 && hw % c.bm == 0 && (c.bm / d.w_in + 2) * (d.w_in + 2) <= CS_SLAB_ROWS && !(d.debug & 8);
 }
 
 static int cg_choose(const AaConvGemm& d, int M) {
@@ -91,6 +103,7 @@ static int cg_choose(const AaConvGemm& d, int M) {
         const CgCfg& c = kCgCfgs[i];
         if (d.n_pad % c.bn) continue;
         if (d.geglu && (c.bn / c.wn) % 64) continue;          // value / gate blocks pair up inside one wavefront
+        if (c.slab && !cg_slab_ok(d, c)) continue;
         if (forced == i) return i;
         const double tiles = (double)((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
         const double slots = 256.0 * c.per_cu;
@@ -104,7 +117,7 @@ static int cg_choose(const AaConvGemm& d, int M) {
 // Split-K factor: few output tiles but a long K loop (the small-M levels) leave most CUs idle behind a serial
 // chain of K steps; spread the K range over up to 8 workgroups per tile (fp32 partials + a reduce launch).
 static int cg_splits(const AaConvGemm& d, int M, const CgCfg& c) {
-    if (d.geglu) return 1;
+    if (d.geglu || c.slab) return 1;
     const int tiles = ((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
     const int slots = 256 * c.per_cu;
     const int nk = d.k_pad / c.bk;
@@ -145,13 +158,14 @@ static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) 
     p.splits = have_workspace_or_query ? cg_splits(d, M, c) : 1;
     if (p.splits > 1) { p.workspace = (size_t)p.splits * M * d.n_pad * 4; return p; }
     p.splits = 1;
-    // One-workgroup-per-CU tiles run in lock-step rounds of 256; a sparsely filled last round wastes most of the chip.
+    // Tiles of one or two workgroups per CU run in lock-step rounds of 256 (512); a sparsely filled last round wastes most of
+    // the chip (the 139264-row level is 2.125 rounds of 256-row tiles AND of 128-row tiles at two per CU).
     // Split it off: full rounds with the big tile; the remaining rows either with the same tile split along K (long K:
     // the leftover tiles x splits fill the chip for nk / splits steps) or with a small (2-3 per CU) tile.
-    if (c.per_cu != 1) return p;
+    if (c.per_cu > 2) return p;
     const int tiles_n = d.n_pad / c.bn;
     const int tiles_m = (M + c.bm - 1) / c.bm;
-    const int cus = (d.debug & 4) ? 2 : 256;              // debug bit 4: pretend a 2-CU chip (exercises the split in tests)
+    const int cus = ((d.debug & 4) ? 2 : 256) * c.per_cu;   // resident slots.  debug bit 4: pretend a 2-CU chip (exercises the split in tests)
     const int rounds = tiles_m * tiles_n / cus;
     const int rem = tiles_m * tiles_n - rounds * cus;
     if (!(rounds >= 1 && rem > 0 && rem * 8 < cus * 5)) return p;
@@ -159,11 +173,11 @@ static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) 
     if (p.m_main >= M) { p.m_main = M; return p; }
     const int nk = d.k_pad / c.bk;
     const int tail_tiles = ((M - p.m_main + c.bm - 1) / c.bm) * tiles_n;
-    int ts = cus / tail_tiles;                            // workgroups available per leftover tile
+    int ts = c.per_cu == 1 ? cus / tail_tiles : 1;        // workgroups available per leftover tile (K splits: one-per-CU tiles only)
     if (ts > 8) ts = 8;                                   // (each split costs a round trip of fp32 partials)
     if (ts > nk / 24) ts = nk / 24;                       // measured: K loops of <= 45 steps are better off with small tiles
     if (have_workspace_or_query && ts >= 2 && !d.geglu) {
-        p.tail_cfg = p.cfg;
+        p.tail_cfg = c.slab ? (c.bn == 320 ? 14 : 15) : p.cfg;       // (the slab kernel does not split K: its im2col twin does)
         p.tail_splits = ts;
         p.workspace = (size_t)ts * (M - p.m_main) * d.n_pad * 4;
         return p;
@@ -182,6 +196,13 @@ static void cg_launch_dma(const AaConvGemm& d, int m_begin, int m_end, int split
     const int tiles_n = d.n_pad / BN;
     const dim3 grid(((m_end - m_begin + BM - 1) / BM) * tiles_n, splits), block(64 * WM * WN);
     AA_LAUNCH((conv_gemm_dma_kernel<T, BM, BN, WM, WN, BK, STAGES, PER_CU, STAGGER, SPREAD>), grid, block, cgd_lds_bytes(BM, BN, BK, STAGES), stream, d, m_end, tiles_n, m_begin, splits);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static void cg_launch_slab(const AaConvGemm& d, int m_begin, int m_end, void* stream) {
+    const int tiles_n = d.n_pad / BN;
+    const dim3 grid(((m_end - m_begin) / BM) * tiles_n), block(64 * WM * WN);
+    AA_LAUNCH((conv3x3_slab_kernel<T, BM, BN, WM, WN>), grid, block, cs_lds_bytes(BN), stream, d, m_end, tiles_n, m_begin);
 }
 
 template <typename T>
@@ -221,6 +242,8 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 31: cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2, false, true>(d, m_begin, m_end, splits, stream); break;
         case 32: cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream); break;
         case 33: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2, false, true>(d, m_begin, m_end, splits, stream); break;
+        case 34: cg_launch_slab<T, 256, 320, 4, 2>(d, m_begin, m_end, stream); break;
+        case 35: cg_launch_slab<T, 256, 256, 4, 2>(d, m_begin, m_end, stream); break;
         default: return false;
     }
     return true;
@@ -315,6 +338,15 @@ int aa_conv_gemm_tile_info(int idx, int32_t info[7]) {
     const aa::CgCfg& c = aa::kCgCfgs[idx];
     info[0] = c.bm; info[1] = c.bn; info[2] = c.wm; info[3] = c.wn; info[4] = c.bk; info[5] = c.stages; info[6] = c.per_cu;
     return 0;
+}
+int aa_conv_gemm_tile_ok(const AaConvGemm* d, int idx) {
+    using namespace aa;
+    if (!d || idx < 0 || idx >= kNumCgCfgs || !cg_dma_ok(*d)) return 0;
+    const CgCfg& c = kCgCfgs[idx];
+    if (d->n_pad % c.bn) return 0;
+    if (d->geglu && (c.bn / c.wn) % 64) return 0;
+    if (c.slab && !cg_slab_ok(*d, c)) return 0;
+    return 1;
 }
 void aa_set_tile_override(int cfg) { aa::g_tile_override = cfg < 0 ? -1 : cfg; }
 const char* aa_last_error(void) { return aa::g_err; }

@@ -30,6 +30,115 @@ __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages)
     return stages * (bm + bn) * bk * 2 + 1024 + 1024;             // + dummy DMA landing zone + the tile's bias slice
 }
 
+// ---- epilogue, straight from the accumulators (no LDS tile, no barrier): shared by the contraction kernels.  The weight
+// fragments were the MFMA "A" operand with their rows permuted by pi, so lane (ec, eh) holds out[m = ec][16*eh + e] in
+// acc[i][j][e] - 16 consecutive columns = two 16-byte stores per block; bias (from LDS), time-embedding row vector, SiLU,
+// GEGLU (value block j, gate block j+1 sit in the same lane) and the residual are applied on the way out.
+//   m_wave  first output row of this wave's blocks          n_wave  first (packed) output column of this wave's blocks
+//   sBiasW  the bias slice of those columns in LDS
+template <typename T, int MI, int NI>
+__device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f32x16 (&acc)[MI][NI], const int m_wave, const int n_wave,
+                                             const T* sBiasW) {
+    const int lane = threadIdx.x & 63;
+    const int ec = lane & 31, eh = lane >> 5;              // lane owns output row ec, columns 16*eh .. +15 of a block
+    const T* rowvec = reinterpret_cast<const T*>(p.rowvec);
+    const T* resid = reinterpret_cast<const T*>(p.residual);
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    T* out = reinterpret_cast<T*>(p.out);
+    const int n_cols = p.geglu ? (p.n_out >> 1) : p.n_out;
+    const bool post = resid || p.out_scale != 1.0f;
+    const bool silu = p.act == AA_ACT_SILU;
+    const bool pre_is_rv = rowvec != nullptr;             // the prefetch registers carry the row vector, else the residual
+#define AA_ZERO4 (u32x4{0u, 0u, 0u, 0u})          /* a prvalue: `c ? arr[i] : zero_variable` would select between ADDRESSES and pin arr in scratch */
+    auto col_of = [&](int j) __attribute__((always_inline)) { return p.geglu ? (n_wave >> 1) + (j >> 1) * 32 + 16 * eh : n_wave + j * 32 + 16 * eh; };
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m_wave + i * 32 + ec;
+        const bool m_ok = m < M;
+        const int mc = m_ok ? m : M - 1;
+        const float brow = (p.bias_per_row && bias) ? (float)bias[mc] : 0.0f;
+        const T* rv = rowvec ? rowvec + (int64_t)(mc / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out) : nullptr;
+        const T* rs = resid ? resid + (int64_t)mc * p.ldr : nullptr;
+        // one block-row of row-vector (or residual) pieces is fetched up front so their latency overlaps
+        u32x4 pre[NI][2];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int n_rv = n_wave + j * 32 + 16 * eh + 8 * q, n_rs = col_of(j) + 8 * q;
+                const bool ok = pre_is_rv ? (n_rv + 8 <= p.n_out) : (rs != nullptr && !(p.geglu && (j & 1)) && n_rs + 8 <= n_cols);
+                const T* src = pre_is_rv ? rv + n_rv : rs + n_rs;
+                pre[j][q] = ok ? *reinterpret_cast<const u32x4*>(src) : AA_ZERO4;
+            }
+        auto finish_block = [&](int j, Pack8<T> (&o)[2]) __attribute__((always_inline)) {   // residual / scale and the two stores of one 32x32 block
+            const int nc = col_of(j);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u32x4 pv = pre[j][q];               // (read unconditionally: a load in only one branch gets merged with the
+                if (post) {                               //  global load of the other into one load through a selected POINTER)
+                    Pack8<T> r; r.raw = AA_ZERO4;
+                    if (rs) { if (pre_is_rv) { if (nc + 8 * q + 8 <= n_cols) r.raw = *reinterpret_cast<const u32x4*>(rs + nc + 8 * q); } else r.raw = pv; }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[q].e[e] = (T)(((float)o[q].e[e] + (float)r.e[e]) * p.out_scale);
+                }
+                if (m_ok && nc + 8 * q + 8 <= n_cols) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o[q].raw;
+            }
+        };
+        auto block_f32 = [&](int j, float (&v)[2][8]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU) in fp32
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                Pack8<T> b; b.raw = *reinterpret_cast<const u32x4*>(sBiasW + (j * 32 + 16 * eh + 8 * q));
+                const u32x4 pv = pre[j][q];
+                Pack8<T> r; r.raw = AA_ZERO4;
+                if (pre_is_rv) r.raw = pv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[q][e] = acc[i][j][8 * q + e] + (float)b.e[e] + brow;
+                if (pre_is_rv) {                          // uniform branches once per eight values, not once per value
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[q][e] += (float)r.e[e];
+                }
+                if (silu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[q][e] = silu_f(v[q][e]);
+                }
+            }
+        };
+        auto block_vals = [&](int j, Pack8<T> (&o)[2]) __attribute__((always_inline)) {     // ... rounded to the storage type
+            float v[2][8];
+            block_f32(j, v);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[q].e[e] = (T)v[q][e];
+        };
+        if (p.geglu) {
+            if constexpr (NI % 2 == 0) {
+#pragma unroll
+                for (int j = 0; j < NI; j += 2) {
+                    // value * gelu(gate) in fp32 on the accumulators, ONE rounding to the storage type
+                    float val[2][8], gate[2][8];
+                    block_f32(j, val);
+                    block_f32(j + 1, gate);
+                    Pack8<T> h[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[q].e[e] = (T)(val[q][e] * gelu_erf_f(gate[q][e]));
+                    finish_block(j, h);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                Pack8<T> o[2];
+                block_vals(j, o);
+                finish_block(j, o);
+            }
+        }
+    }
+#undef AA_ZERO4
+}
+
 // PER_CU = workgroups meant to be co-resident on a CU (register budget: 512 / (PER_CU * waves per SIMD)).
 // SPREAD: a wave's DMA share of the next tile is not issued in one burst but in pieces in front of the first k sub-steps of
 // its multiply (each piece queues in the CU-wide LDS-DMA issue path while the wave's previous MFMAs still occupy the matrix pipe).
@@ -414,108 +523,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         return;
     }
 
-    // ---- epilogue, straight from the accumulators (no LDS tile, no barrier): the weight fragments were the MFMA
-    // "A" operand with their rows permuted by pi, so lane (ec, eh) holds out[m = ec][16*eh + e] in acc[i][j][e] -
-    // 16 consecutive columns = two 16-byte stores per block; bias (from LDS), time-embedding row vector, SiLU,
-    // GEGLU (value block j, gate block j+1 sit in the same lane) and the residual are applied on the way out.
-    const T* rowvec = reinterpret_cast<const T*>(p.rowvec);
-    const T* resid = reinterpret_cast<const T*>(p.residual);
-    const T* bias = reinterpret_cast<const T*>(p.bias);
-    T* out = reinterpret_cast<T*>(p.out);
-    const int n_cols = p.geglu ? (p.n_out >> 1) : p.n_out;
-    const bool post = resid || p.out_scale != 1.0f;
-    const bool silu = p.act == AA_ACT_SILU;
-    const bool pre_is_rv = rowvec != nullptr;             // the prefetch registers carry the row vector, else the residual
-#define AA_ZERO4 (u32x4{0u, 0u, 0u, 0u})          /* a prvalue: `c ? arr[i] : zero_variable` would select between ADDRESSES and pin arr in scratch */
-    auto col_of = [&](int j) __attribute__((always_inline)) { return p.geglu ? (n_wave >> 1) + (j >> 1) * 32 + 16 * eh : n_wave + j * 32 + 16 * eh; };
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m_tile + wm * (BM / WM) + i * 32 + ec;
-        const bool m_ok = m < M;
-        const int mc = m_ok ? m : M - 1;
-        const float brow = (p.bias_per_row && bias) ? (float)bias[mc] : 0.0f;
-        const T* rv = rowvec ? rowvec + (int64_t)(mc / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out) : nullptr;
-        const T* rs = resid ? resid + (int64_t)mc * p.ldr : nullptr;
-        // one block-row of row-vector (or residual) pieces is fetched up front so their latency overlaps
-        u32x4 pre[NI][2];
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int n_rv = n_wave + j * 32 + 16 * eh + 8 * q, n_rs = col_of(j) + 8 * q;
-                const bool ok = pre_is_rv ? (n_rv + 8 <= p.n_out) : (rs != nullptr && !(p.geglu && (j & 1)) && n_rs + 8 <= n_cols);
-                const T* src = pre_is_rv ? rv + n_rv : rs + n_rs;
-                pre[j][q] = ok ? *reinterpret_cast<const u32x4*>(src) : AA_ZERO4;
-            }
-        auto finish_block = [&](int j, Pack8<T> (&o)[2]) __attribute__((always_inline)) {   // residual / scale and the two stores of one 32x32 block
-            const int nc = col_of(j);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const u32x4 pv = pre[j][q];               // (read unconditionally: a load in only one branch gets merged with the
-                if (post) {                               //  global load of the other into one load through a selected POINTER)
-                    Pack8<T> r; r.raw = AA_ZERO4;
-                    if (rs) { if (pre_is_rv) { if (nc + 8 * q + 8 <= n_cols) r.raw = *reinterpret_cast<const u32x4*>(rs + nc + 8 * q); } else r.raw = pv; }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[q].e[e] = (T)(((float)o[q].e[e] + (float)r.e[e]) * p.out_scale);
-                }
-                if (m_ok && nc + 8 * q + 8 <= n_cols) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o[q].raw;
-            }
-        };
-        auto block_f32 = [&](int j, float (&v)[2][8]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU) in fp32
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                Pack8<T> b; b.raw = *reinterpret_cast<const u32x4*>(sBias + (wn * (BN / WN) + j * 32 + 16 * eh + 8 * q));
-                const u32x4 pv = pre[j][q];
-                Pack8<T> r; r.raw = AA_ZERO4;
-                if (pre_is_rv) r.raw = pv;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[q][e] = acc[i][j][8 * q + e] + (float)b.e[e] + brow;
-                if (pre_is_rv) {                          // uniform branches once per eight values, not once per value
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[q][e] += (float)r.e[e];
-                }
-                if (silu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[q][e] = silu_f(v[q][e]);
-                }
-            }
-        };
-        auto block_vals = [&](int j, Pack8<T> (&o)[2]) __attribute__((always_inline)) {     // ... rounded to the storage type
-            float v[2][8];
-            block_f32(j, v);
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[q].e[e] = (T)v[q][e];
-        };
-        if (p.geglu) {
-            if constexpr (NI % 2 == 0) {
-#pragma unroll
-                for (int j = 0; j < NI; j += 2) {
-                    // value * gelu(gate) in fp32 on the accumulators, ONE rounding to the storage type
-                    float val[2][8], gate[2][8];
-                    block_f32(j, val);
-                    block_f32(j + 1, gate);
-                    Pack8<T> h[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) h[q].e[e] = (T)(val[q][e] * gelu_erf_f(gate[q][e]));
-                    finish_block(j, h);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                Pack8<T> o[2];
-                block_vals(j, o);
-                finish_block(j, o);
-            }
-        }
-        if (i == 0) stamp(3);
-    }
+    cgd_epilogue<T, MI, NI>(p, M, acc, m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN));
     stamp(5);
-#undef AA_ZERO4
 }
 
 }  // namespace aa

@@ -119,12 +119,13 @@ def _tile_candidates(d, rows):
     if not dma:
         return []
     out = []
+    lib = _lib.get()
     for i, (bm, bn, bk, _st) in enumerate(TILE_TABLE):
-        if d.n_pad % bn:
-            continue
-        if d.geglu and (bn // TILE_TABLE.wave_cols(i)) % 64:            # value / gate blocks pair up inside one wavefront
+        if not lib.aa_conv_gemm_tile_ok(C.byref(d), i):                 # width, GEGLU pairing, slab-kernel geometry
             continue
         out.append((i, 0))
+        if bk == 32 and _st == 3:                                       # halo-slab kernel: no K split
+            continue
         if d.geglu or bm < 128:
             continue
         tiles = -(-rows // bm) * (d.n_pad // bn)

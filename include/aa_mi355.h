@@ -104,6 +104,10 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream);
  * rows, wave columns, K step, ring stages, workgroups per CU of entry `idx`; returns 0, or -1 past the end of the table. */
 int aa_conv_gemm_tile_info(int idx, int32_t info[7]);
 
+/* 1 when entry `idx` of the tile table can carry out this call (packed width divisible by the tile, GEGLU pairing, the
+ * geometry preconditions of the halo-slab 3x3 kernel), else 0: what an autotuner should restrict itself to. */
+int aa_conv_gemm_tile_ok(const AaConvGemm* d, int idx);
+
 /* Tuning / test aid: force tile shape `cfg` (index into the table in csrc/aa_api_impl.h) for every
  * following aa_conv_gemm call OF THE CALLING THREAD whose packed width it divides; cfg < 0 restores the automatic
  * choice (thread-local, like aa_last_error: the library keeps no process-global mutable state). */

@@ -375,15 +375,17 @@ def test_rowvec_is_a_column_slice_of_a_wider_matrix(backend):
     close(y, nhwc(ref))
 
 
-def test_sparse_last_round_is_split_to_small_tiles(backend):
-    """Big-tile launches hand a sparsely filled last round of tiles to a small-tile launch (m_begin path)."""
+@pytest.mark.parametrize("big", [4, 30])
+def test_sparse_last_round_is_split_to_small_tiles(backend, big):
+    """Big-tile launches (one per CU: 256x320; two per CU: 128x320) hand a sparsely filled last round of tiles to a small-tile
+    launch (m_begin path)."""
     from animate_anything_amd import _lib
     n, h, w, cin, N = 3, 15, 16, 64, 320              # M = 720 rows: 2 full 256-row tiles + 208 left over
     x, wt, b = rnd(n, cin, h, w, seed=71), rnd(N, cin, 3, 3, scale=0.05, seed=72), rnd(N, seed=73)
     g = ops.conv3x3_geom(n, h, w)
     res = rnd(g.rows, N, seed=74)
     lib = _lib.get()
-    lib.aa_set_tile_override(4)
+    lib.aa_set_tile_override(big)
     ops.DEBUG_ABLATE = 4
     try:
         y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res)
@@ -488,3 +490,46 @@ def test_attention_head_dim_8(backend, L):
     x = qkv.reshape(n, L, 3, heads, 8).permute(2, 0, 3, 1, 4)
     ref = sdpa(x[0], x[1], x[2]).permute(0, 2, 1, 3).reshape(n * L, C)
     close(o, ref, tol=1e-2)
+
+
+@pytest.mark.parametrize("cfg,N", [(34, 320), (35, 256)])
+@pytest.mark.parametrize("h,w,c0,c1", [(16, 16, 128, 0), (8, 32, 64, 64), (4, 64, 192, 0), (32, 16, 64, 0)])
+def test_conv3x3_halo_slab_kernel(backend, cfg, N, h, w, c0, c1):
+    """The halo-slab 3x3 kernel (tile = whole image rows, nine taps as views of one staged slab): all three slab
+    geometries of the benchmark (W = 16 / 32 / 64), image borders, two-source concat, several images / tiles per image,
+    row vector + SiLU + residual epilogue."""
+    from animate_anything_amd import _lib
+    n = 2
+    cin = c0 + c1
+    x, wt, b = rnd(n, cin, h, w, seed=181), rnd(N, cin, 3, 3, scale=0.04, seed=182), rnd(N, seed=183)
+    g = ops.conv3x3_geom(n, h, w)
+    res, temb = rnd(g.rows, N, seed=184), rnd(n, N, seed=185)
+    tok = nhwc(x)
+    x0, x1 = (tok, None) if c1 == 0 else (tok[:, :c0].contiguous(), tok[:, c0:].contiguous())
+    lib = _lib.get()
+    pw = ops.pack_weight(wt, b)
+    assert pw.k_order == 1
+    lib.aa_set_tile_override(cfg)
+    try:
+        y = ops.conv_gemm(x0, pw, g, x1=x1, residual=res, rowvec=temb, rowvec_div=h * w, act=AA_ACT_SILU)
+    finally:
+        lib.aa_set_tile_override(-1)
+    ref = nhwc(F.silu(F.conv2d(x.float(), wt.float(), b.float(), padding=1) + temb.float()[:, :, None, None])).half().float() + res.float()
+    close(y, ref)
+
+
+def test_halo_slab_eligibility(emu):
+    """aa_conv_gemm_tile_ok: the slab entries are offered only for 3x3 / stride 1 / whole-image-row tiles."""
+    import ctypes as C
+    from animate_anything_amd import _lib
+    from animate_anything_amd._lib import AaConvGemm
+    lib = _lib.get()
+    d = AaConvGemm()
+    d.c0, d.c1, d.n_img, d.h_in, d.w_in, d.h_virt, d.w_virt, d.h_out, d.w_out = 320, 0, 34, 64, 64, 64, 64, 64, 64
+    d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.n_out, d.n_pad, d.k_pad, d.k_order = 3, 3, 1, 1, 1, 320, 320, 2880, 1
+    d.ldo, d.dtype, d.out_dtype = 320, 0, 0
+    assert lib.aa_conv_gemm_tile_ok(C.byref(d), 34) == 1 and lib.aa_conv_gemm_tile_ok(C.byref(d), 35) == 0   # 320 % 256
+    d.stride = 2
+    assert lib.aa_conv_gemm_tile_ok(C.byref(d), 34) == 0
+    d.stride, d.h_in, d.w_in, d.h_virt, d.w_virt, d.h_out, d.w_out = 1, 55, 74, 55, 74, 55, 74                  # irregular eval size
+    assert lib.aa_conv_gemm_tile_ok(C.byref(d), 34) == 0 and lib.aa_conv_gemm_tile_ok(C.byref(d), 14) == 1
