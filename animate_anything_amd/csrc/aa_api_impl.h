@@ -323,7 +323,8 @@ static int attention_t(const AaAttention& d, void* stream) {
         AA_LAUNCH((attention_kernel<T, 4>), grid, dim3(256), attn_lds_bytes(d.kv_len), stream, d);
     } else {
         const dim3 grid((d.q_len + 31) / 32, d.heads, nseq);
-        AA_LAUNCH((attention_kernel<T, 1>), grid, dim3(64), attn_lds_bytes(d.kv_len), stream, d);
+        if (d.kv_len <= 32) AA_LAUNCH((attention_kernel<T, 1, 32>), grid, dim3(64), AT_TILE_BYTES / 2, stream, d);
+        else                AA_LAUNCH((attention_kernel<T, 1>), grid, dim3(64), attn_lds_bytes(d.kv_len), stream, d);
     }
     return finish("attention");
 }

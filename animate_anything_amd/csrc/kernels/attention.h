@@ -49,9 +49,15 @@ __host__ __device__ inline int64_t attn_extent_bytes(const AaAttnOperand& x, int
     return (last + 1) * x.ld * 2;
 }
 
-template <typename T, int NW>
-__global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(const AaAttention p) {
-    constexpr int PER = 16 / NW;                 // DMA instructions per wave and tile (8 for K + 8 for V in total)
+// KT = keys per tile: 64, or 32 for single-tile sequences of at most 32 keys (the T' = 17 temporal attention: half the LDS,
+// half the DMA instructions and half the MFMAs of a 64-key tile whose second half would be masked anyway; one-wave
+// workgroups at four per SIMD - that kernel is bound by how many independent sequences a CU keeps in flight).
+template <typename T, int NW, int KT = 64>
+__global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) attention_kernel(const AaAttention p) {
+    constexpr int PER = (KT / 4) / NW;           // DMA instructions per wave and tile (KT/8 for K + KT/8 for V in total)
+    constexpr int KB = KT / 32;                  // 32-key blocks per tile
+    constexpr int TILE_BYTES = 2 * KT * 128;
+    static_assert(KT == 64 || (KT == 32 && NW == 1), "tile");
     constexpr unsigned OOB = 0x80000000u;
     char* lds = dyn_smem();
 
@@ -106,19 +112,19 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
     }
     int next_tile_key0 = 0;                      // issue() is called for consecutive tiles
     auto issue = [&](int buf) {
-        char* sK = lds + buf * AT_TILE_BYTES;
-        char* sV = sK + AT_KT * 128;
+        char* sK = lds + buf * TILE_BYTES;
+        char* sV = sK + KT * 128;
         const int rem = p.kv_len - next_tile_key0;                        // keys left from this tile on
-        next_tile_key0 += AT_KT;
+        next_tile_key0 += KT;
 #pragma unroll
         for (int j = 0; j < PER / 2; ++j) {
             async_copy16_buf(r_k, klocal[j] < rem ? koff[j] : OOB, sK + (wave * (PER / 2) + j) * 1024);
-            koff[j] += AT_KT * k_key;
+            koff[j] += KT * k_key;
         }
 #pragma unroll
         for (int j = 0; j < PER / 2; ++j) {
             async_copy16_buf(r_v, vlocal[j] < rem ? voff[j] : OOB, sV + (wave * (PER / 2) + j) * 1024);
-            voff[j] += AT_KT * v_key;
+            voff[j] += KT * v_key;
         }
     };
 
@@ -127,8 +133,8 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
     for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.0f; oacc[1][e] = 0.0f; }
     float m_run = 0.0f, l_run = 0.0f;           // running (lazily moved) max of the scaled scores, running sum of this half-wave's keys
 
-    const int ntiles = (p.kv_len + AT_KT - 1) / AT_KT;
-    const bool ragged = (p.kv_len & (AT_KT - 1)) != 0;
+    const int ntiles = (p.kv_len + KT - 1) / KT;
+    const bool ragged = (p.kv_len & (KT - 1)) != 0;
     const int stages = attn_stages(p.kv_len);   // 3 (two tiles in flight ahead of the math) or 1 (single tile)
     issue(0);
     if (ntiles > 1) issue(1);
@@ -140,46 +146,52 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
         block_barrier();                                                  // everyone's pieces; buffer (kt-1)%3 is free again
         if (kt + 2 < ntiles) issue((kt + 2) % 3);
         if (wave_active) {
-            const char* sK = lds + (stages == 1 ? 0 : (kt % 3)) * AT_TILE_BYTES;
-            const char* sV = sK + AT_KT * 128;
+            const char* sK = lds + (stages == 1 ? 0 : (kt % 3)) * TILE_BYTES;
+            const char* sV = sK + KT * 128;
             // S^T - m: the accumulators start at minus the running maximum (zero for the first tile)
             const float acc0 = kt == 0 ? 0.0f : -m_run;
-            f32x16 sacc[2];
+            f32x16 sacc[KB];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { sacc[0][e] = acc0; sacc[1][e] = acc0; }
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[kb][e] = acc0;
             // the two 32-key blocks alternate so that consecutive MFMAs never wait on each other's accumulator
 #pragma unroll
             for (int dk = 0; dk < 4; ++dk)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
+                for (int kb = 0; kb < KB; ++kb) {
                     const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + kb * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
                     sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], sacc[kb]);
                 }
             if (ragged && kt == ntiles - 1) {           // mask the keys past kv_len (last tile only)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int key = kt * AT_KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const int key = kt * KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
                         if (key >= p.kv_len) sacc[kb][e] = -1.0e30f;
                     }
             }
             // row max of (score - m): four independent chains, then a tree (a single 32-long fmax chain is pure latency)
-            float mx[4];
+            float mx[2 * KB];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) mx[c] = fmaxf(sacc[c >> 1][8 * (c & 1)], sacc[c >> 1][8 * (c & 1) + 1]);
+            for (int c = 0; c < 2 * KB; ++c) mx[c] = fmaxf(sacc[c >> 1][8 * (c & 1)], sacc[c >> 1][8 * (c & 1) + 1]);
 #pragma unroll
             for (int e = 2; e < 8; ++e)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) mx[c] = fmaxf(mx[c], sacc[c >> 1][8 * (c & 1) + e]);
-            const float over = wave_max_halves(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
+                for (int c = 0; c < 2 * KB; ++c) mx[c] = fmaxf(mx[c], sacc[c >> 1][8 * (c & 1) + e]);
+            float mall = fmaxf(mx[0], mx[1]);
+            if constexpr (KB == 2) mall = fmaxf(mall, fmaxf(mx[2], mx[3]));
+            const float over = wave_max_halves(mall);
             if (kt == 0 || wave_any(over > AT_DEFER)) {
                 // move the maximum (rare after the first tiles): everything still at the old maximum - O, l and this tile's
                 // scores, which have NOT been exponentiated yet - is rescaled exactly once
                 const float delta = kt == 0 ? over : fmaxf(over, 0.0f);
                 m_run += delta;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { sacc[0][e] -= delta; sacc[1][e] -= delta; }
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sacc[kb][e] -= delta;
                 if (kt != 0) {
                     const float alpha = fast_exp2(-delta);
                     l_run *= alpha;
@@ -188,10 +200,12 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
                 }
             }
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            f32x2 ps2[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};      // packed partial row sums
-            u32x4 pf[4];
+            f32x2 ps2[2 * KB];                                                          // packed partial row sums
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int c = 0; c < 2 * KB; ++c) ps2[c] = f32x2{0.0f, 0.0f};
+            u32x4 pf[2 * KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     Pack8<T> pk;
@@ -206,13 +220,14 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : 2) attention_kernel(cons
                     }
                     pf[2 * kb + c] = pk.raw;
                 }
-            const f32x2 pst = (ps2[0] + ps2[1]) + (ps2[2] + ps2[3]);
+            f32x2 pst = ps2[0] + ps2[1];
+            if constexpr (KB == 2) pst += ps2[2] + ps2[3];
             const float psum = pst[0] + pst[1];
             l_run += psum;
             // O^T += V^T P^T: chunk ch = 16 keys; this half-wave's 8 k-slots are keys 16ch + 4h + {0..3} and
             // 16ch + 8 + 4h + {0..3} (the order P^T's registers came out of the S^T accumulator layout)
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
+            for (int ch = 0; ch < 2 * KB; ++ch)
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const char* base = sV + (2 * ch) * 1024 + db * 256 + vf_off;
