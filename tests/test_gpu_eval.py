@@ -54,3 +54,32 @@ def test_eval_driver_roundtrip(tmp_path):
     assert latents.shape == (1, 4, 4, 14, 18) and torch.isfinite(latents).all()
     assert os.path.exists(tmp_path / "out" / "img" / "0.gif") and os.path.exists(tmp_path / "out" / "img" / "1.gif")
     assert Image.open(tmp_path / "out" / "img" / "0.gif").n_frames == 4
+
+    # ---- the same sample through the CPU oracle (reference flow train.py:731-791 restated with oracle modules): same
+    # checkpoint, same image / mask preprocessing, the SAME initial noise (first draw of the seeded GPU generator), same
+    # prompt embeddings, motion strength index+3, DPM-Solver++ timesteps -> final latents must agree (fp16 bar: MSE < 1e-3)
+    import oracle
+    from safetensors.torch import load_file
+    ounet = oracle.UNet3DConditionModel(**SMALL_UNET).eval()
+    ounet.load_state_dict(load_file(str(ckpt / "unet" / "diffusion_pytorch_model.safetensors")))
+    ovae = oracle.AutoencoderKL(**SMALL_VAE).eval()
+    ovae.load_state_dict(load_file(str(ckpt / "vae" / "diffusion_pytorch_model.safetensors")))
+    h, w, frames_n, steps = 112, 144, 4, 3
+    img = aa_eval.preprocess_image(Image.open(tmp_path / "img.jpg").convert("RGB"), h, w)
+    with torch.no_grad():
+        x0 = oracle.tensor_to_vae_latent(img[None], ovae)                                    # [1,4,1,14,18]
+    g = torch.Generator(device="cuda").manual_seed(7)
+    noise = torch.randn((1, 4, frames_n, h // 8, w // 8), dtype=torch.float16, device="cuda", generator=g).float().cpu()
+    osched = oracle.DPMSolverMultistepScheduler()
+    osched.set_timesteps(steps)
+    init = oracle.ddpm_add_noise(x0.repeat(1, 1, frames_n, 1, 1), noise, int(osched.timesteps[0]))
+    np_mask = np.array(Image.open(tmp_path / "img_label.jpg").resize((w, h)))
+    np_mask[np_mask != 0] = 255
+    mask = aa_eval.mask_to_latent(np_mask, h // 8, w // 8)
+    emb = torch.load(tmp_path / "embeds.pt")
+    _, want = oracle.LatentToVideoPipeline(ovae, ounet, osched)(
+        latents=init, prompt_embeds=emb["prompt_embeds"], negative_prompt_embeds=emb["negative_prompt_embeds"],
+        condition_latent=x0, mask=mask, motion=[3], num_inference_steps=steps, guidance_scale=9.0, return_dict=False,
+        timesteps=osched.timesteps)
+    mse = ((latents.float().cpu() - want) ** 2).mean().item()
+    assert mse < 1e-3, mse

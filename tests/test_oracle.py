@@ -100,3 +100,21 @@ def test_guidance_le_one_does_not_double_batch():
             latents=lat, prompt_embeds=torch.zeros(1, 7, 16), negative_prompt_embeds=torch.zeros(1, 7, 16),
             condition_latent=cond, mask=None, motion=None, num_inference_steps=2, guidance_scale=g, return_dict=False)
         assert seen and all(s == want for s in seen)
+
+
+def test_oracle_fp64_agrees_with_fp32():
+    """The oracle cannot be pinned to the reference (diffusers is absent on the build AND the GPU box:
+    profiles/r02_oracle_pin_probe.log), so at least its own arithmetic must not be the limiting error of a parity test: the
+    fp32 oracle agrees with itself in fp64 four orders of magnitude below the fp16 tolerance (3e-2) the GPU tests use."""
+    import copy
+    torch.manual_seed(0)
+    ref = oracle.UNet3DConditionModel(**TINY_UNET).eval()
+    ref.load_state_dict(seeded_state(ref))
+    ref64 = copy.deepcopy(ref).double()
+    i = unet_inputs(h=6, w=6, text_len=9)
+    with torch.no_grad():
+        a = ref(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
+        b = ref64(i["sample"].double(), i["t"], i["text"].double(), i["cond"].double(), i["mask"].double(),
+                  motion=i["motion"].double()).sample
+    err = ((a.double() - b).abs().max() / b.abs().max()).item()
+    assert err < 1e-5, err
