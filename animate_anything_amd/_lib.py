@@ -27,7 +27,6 @@ class AaConvGemm(C.Structure):
         ("rowvec_div", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
         ("act", C.c_int32), ("geglu", C.c_int32), ("bias_per_row", C.c_int32),
         ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("k_order", C.c_int32), ("debug", C.c_int32), ("tile", C.c_int32), ("k_splits", C.c_int32), ("rowvec_ld", C.c_int32),
-        ("row_stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_chunks", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 

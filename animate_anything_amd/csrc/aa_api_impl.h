@@ -104,7 +104,6 @@ static int cg_choose(const AaConvGemm& d, int M) {
         if (d.n_pad % c.bn) continue;
         if (d.geglu && (c.bn / c.wn) % 64) continue;          // value / gate blocks pair up inside one wavefront
         if (c.slab && !cg_slab_ok(d, c)) continue;
-        if (d.row_stats_out && !(c.bn == 320 && c.wn == 2 && !c.slab)) continue;   // 160 columns per wavefront
         if (forced == i) return i;
         const double tiles = (double)((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
         const double slots = 256.0 * c.per_cu;
@@ -118,7 +117,7 @@ static int cg_choose(const AaConvGemm& d, int M) {
 // Split-K factor: few output tiles but a long K loop (the small-M levels) leave most CUs idle behind a serial
 // chain of K steps; spread the K range over up to 8 workgroups per tile (fp32 partials + a reduce launch).
 static int cg_splits(const AaConvGemm& d, int M, const CgCfg& c) {
-    if (d.geglu || c.slab || d.row_stats_out || d.ln_stats) return 1;
+    if (d.geglu || c.slab) return 1;
     const int tiles = ((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
     const int slots = 256 * c.per_cu;
     const int nk = d.k_pad / c.bk;
@@ -174,7 +173,7 @@ static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) 
     if (p.m_main >= M) { p.m_main = M; return p; }
     const int nk = d.k_pad / c.bk;
     const int tail_tiles = ((M - p.m_main + c.bm - 1) / c.bm) * tiles_n;
-    int ts = (c.per_cu == 1 && !d.row_stats_out && !d.ln_stats) ? cus / tail_tiles : 1;   // workgroups available per leftover tile (K splits: one-per-CU tiles only)
+    int ts = c.per_cu == 1 ? cus / tail_tiles : 1;        // workgroups available per leftover tile (K splits: one-per-CU tiles only)
     if (ts > 8) ts = 8;                                   // (each split costs a round trip of fp32 partials)
     if (ts > nk / 24) ts = nk / 24;                       // measured: K loops of <= 45 steps are better off with small tiles
     if (have_workspace_or_query && ts >= 2 && !d.geglu) {
@@ -183,7 +182,6 @@ static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) 
         p.workspace = (size_t)ts * (M - p.m_main) * d.n_pad * 4;
         return p;
     }
-    if (d.row_stats_out) { p.tail_cfg = 11; return p; }   // row statistics need 160 columns per wavefront: 128x320, two per CU
     const int small[2] = {1, 0};
     for (int k = 0; k < 2 && p.tail_cfg < 0; ++k) {
         const CgCfg& t = kCgCfgs[small[k]];
@@ -279,7 +277,6 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
         return finish("conv_gemm");
     }
     if (d.geglu) return fail(AA_E_SHAPE, "conv_gemm: GEGLU needs the LDS-DMA path (channels %% 64 == 0, 16-byte rows)");
-    if (d.row_stats_out || d.ln_stats) return fail(AA_E_SHAPE, "conv_gemm: folded LayerNorm needs the LDS-DMA path (channels %% 64 == 0, 16-byte rows)");
     if (d.k_order) return fail(AA_E_SHAPE, "conv_gemm: chunk-major weights need the LDS-DMA path (channels %% 64 == 0, 16-byte rows)");
     // generic gather path (odd channel counts: conv_in2, conv_out, VAE stem / head, fp32 scores)
     const bool bn128 = (d.n_pad % 128 == 0);
@@ -350,7 +347,6 @@ int aa_conv_gemm_tile_ok(const AaConvGemm* d, int idx) {
     if (d->n_pad % c.bn) return 0;
     if (d->geglu && (c.bn / c.wn) % 64) return 0;
     if (c.slab && !cg_slab_ok(*d, c)) return 0;
-    if (d->row_stats_out && !(c.bn == 320 && c.wn == 2 && !c.slab)) return 0;
     return 1;
 }
 void aa_set_tile_override(int cfg) { aa::g_tile_override = cfg < 0 ? -1 : cfg; }
@@ -377,10 +373,6 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream) {
     if (d->geglu && (d->geglu != 32 || d->n_out != d->n_pad || d->bias_per_row))
         return fail(AA_E_SHAPE, "conv_gemm: GEGLU packs (32 value | 32 gate) column blocks, n_out == n_pad (geglu=%d n_out=%d)", d->geglu, d->n_out);
     if ((int64_t)d->n_img * d->h_out * d->w_out >= (int64_t)1 << 31) return fail(AA_E_SHAPE, "conv_gemm: M overflows int32");
-    if (d->row_stats_out && (d->geglu || d->n_out % 160 || d->n_pad % 320 || d->out_dtype != d->dtype))
-        return fail(AA_E_SHAPE, "conv_gemm: row_stats_out needs n_out %% 160 == 0, a 320-column tiling and no GEGLU (n_out=%d)", d->n_out);
-    if (d->ln_stats && (!d->ln_colsum || d->ln_chunks < 1 || d->ln_chunks > 64 || d->kh * d->kw != 1))
-        return fail(AA_E_SHAPE, "conv_gemm: folded LayerNorm needs ln_colsum, 1 <= ln_chunks <= 64 and a linear layer");
     if (!aligned16(d->a0) || !aligned16(d->a1) || !aligned16(d->w)) return fail(AA_E_ALIGN, "conv_gemm: operands must be 16-byte aligned");
     if (d->out_dtype != AA_F32 && d->out_dtype != d->dtype) return fail(AA_E_DTYPE, "conv_gemm: out_dtype must be dtype or f32");
     if (d->dtype == AA_F16) return conv_gemm_t<f16_t>(*d, stream);

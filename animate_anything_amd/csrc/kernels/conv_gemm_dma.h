@@ -27,7 +27,7 @@
 namespace aa {
 
 __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages) {
-    return stages * (bm + bn) * bk * 2 + 1024 + 1024 + 2048;      // + dummy DMA landing zone + the tile's bias slice + its LayerNorm column sums
+    return stages * (bm + bn) * bk * 2 + 1024 + 1024;             // + dummy DMA landing zone + the tile's bias slice
 }
 
 // ---- epilogue, straight from the accumulators (no LDS tile, no barrier): shared by the contraction kernels.  The weight
@@ -35,14 +35,10 @@ __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages)
 // acc[i][j][e] - 16 consecutive columns = two 16-byte stores per block; bias (from LDS), time-embedding row vector, SiLU,
 // GEGLU (value block j, gate block j+1 sit in the same lane) and the residual are applied on the way out.
 //   m_wave  first output row of this wave's blocks          n_wave  first (packed) output column of this wave's blocks
-//   sBiasW  the bias slice of those columns in LDS            sColW   their LayerNorm column sums (fp32), or nullptr
-// LayerNorm folded into a linear layer (AaConvGemm.ln_stats): the weights carry gamma, the bias carries W.beta, and with
-// s_n = sum_c W'[n][c] the normalised product is  rstd_r * (acc[r][n] - mean_r * s_n) + b'_n  - the row statistics come from
-// the PRODUCER of the activation (AaConvGemm.row_stats_out: in this accumulator layout a lane owns an output row, so the
-// row sums are lane-local adds plus one half-wave exchange), no LayerNorm pass over the tensor.
+//   sBiasW  the bias slice of those columns in LDS
 template <typename T, int MI, int NI>
 __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f32x16 (&acc)[MI][NI], const int m_wave, const int n_wave,
-                                             const T* sBiasW, const float* sColW = nullptr) {
+                                             const T* sBiasW) {
     const int lane = threadIdx.x & 63;
     const int ec = lane & 31, eh = lane >> 5;              // lane owns output row ec, columns 16*eh .. +15 of a block
     const T* rowvec = reinterpret_cast<const T*>(p.rowvec);
@@ -53,9 +49,6 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
     const bool post = resid || p.out_scale != 1.0f;
     const bool silu = p.act == AA_ACT_SILU;
     const bool pre_is_rv = rowvec != nullptr;             // the prefetch registers carry the row vector, else the residual
-    const bool ln = sColW != nullptr;
-    const float* ln_stats = reinterpret_cast<const float*>(p.ln_stats);
-    float* row_stats = reinterpret_cast<float*>(p.row_stats_out);
 #define AA_ZERO4 (u32x4{0u, 0u, 0u, 0u})          /* a prvalue: `c ? arr[i] : zero_variable` would select between ADDRESSES and pin arr in scratch */
     auto col_of = [&](int j) __attribute__((always_inline)) { return p.geglu ? (n_wave >> 1) + (j >> 1) * 32 + 16 * eh : n_wave + j * 32 + 16 * eh; };
 #pragma unroll
@@ -66,15 +59,6 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
         const float brow = (p.bias_per_row && bias) ? (float)bias[mc] : 0.0f;
         const T* rv = rowvec ? rowvec + (int64_t)(mc / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out) : nullptr;
         const T* rs = resid ? resid + (int64_t)mc * p.ldr : nullptr;
-        float ln_mean = 0.0f, ln_rstd = 1.0f, rs1 = 0.0f, rs2 = 0.0f;
-        if (ln) {                                          // LayerNorm statistics of input row m from its producer's chunk sums
-            const float* st = ln_stats + (int64_t)mc * p.ln_chunks * 2;
-            float s1 = 0.0f, s2 = 0.0f;
-            for (int ch = 0; ch < p.ln_chunks; ++ch) { s1 += st[2 * ch]; s2 += st[2 * ch + 1]; }
-            const float inv_c = 1.0f / (float)(p.c0 + p.c1);
-            ln_mean = s1 * inv_c;
-            ln_rstd = rsqrtf(fmaxf(s2 * inv_c - ln_mean * ln_mean, 0.0f) + p.ln_eps);
-        }
         // one block-row of row-vector (or residual) pieces is fetched up front so their latency overlaps
         u32x4 pre[NI][2];
 #pragma unroll
@@ -98,10 +82,6 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
                     for (int e = 0; e < 8; ++e) o[q].e[e] = (T)(((float)o[q].e[e] + (float)r.e[e]) * p.out_scale);
                 }
                 if (m_ok && nc + 8 * q + 8 <= n_cols) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o[q].raw;
-                if (row_stats) {                          // sums of the STORED values (what the consumer will read)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float f = (float)o[q].e[e]; rs1 += f; rs2 = __builtin_fmaf(f, f, rs2); }
-                }
             }
         };
         auto block_f32 = [&](int j, float (&v)[2][8]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU) in fp32
@@ -111,16 +91,8 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
                 const u32x4 pv = pre[j][q];
                 Pack8<T> r; r.raw = AA_ZERO4;
                 if (pre_is_rv) r.raw = pv;
-                if (ln) {
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(sColW + (j * 32 + 16 * eh + 8 * q));
-                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(sColW + (j * 32 + 16 * eh + 8 * q) + 4);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        v[q][e] = __builtin_fmaf(acc[i][j][8 * q + e] - ln_mean * (e < 4 ? c0[e & 3] : c1[e & 3]), ln_rstd, (float)b.e[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[q][e] = acc[i][j][8 * q + e] + (float)b.e[e] + brow;
-                }
+                for (int e = 0; e < 8; ++e) v[q][e] = acc[i][j][8 * q + e] + (float)b.e[e] + brow;
                 if (pre_is_rv) {                          // uniform branches once per eight values, not once per value
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[q][e] += (float)r.e[e];
@@ -163,13 +135,6 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
                 finish_block(j, o);
             }
         }
-        if (row_stats) {                                   // this wave's 160 columns of row m: both half-waves joined, one 8-byte store
-            const float t1 = wave_sum_halves(rs1), t2 = wave_sum_halves(rs2);
-            if (m_ok && eh == 0) {
-                float* dst = row_stats + ((int64_t)m * (n_cols / 160) + n_wave / 160) * 2;
-                dst[0] = t1; dst[1] = t2;
-            }
-        }
     }
 #undef AA_ZERO4
 }
@@ -205,8 +170,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     char* smem = dyn_smem();
     char* dummy = smem + STAGES * STAGE_BYTES;           // where surplus (guarded-out) DMA instructions land
     T* sBias = reinterpret_cast<T*>(dummy + 1024);       // bias of the tile's BN columns (the K-loop barriers publish it)
-    float* sCol = reinterpret_cast<float*>(dummy + 2048); // LayerNorm column sums of the tile's columns (folded-LN calls)
-    static_assert(BN * 2 <= 1024 && BN * 4 <= 2048, "bias / column-sum slices");
+    static_assert(BN * 2 <= 1024, "bias slice");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -225,17 +189,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         if ((p.debug & 8) && tid == 0) reinterpret_cast<long long*>(p.workspace)[(int64_t)blockIdx.x * 8 + slot] = clock_now();
     };
     stamp(0);
-    if (tid < BN / 8) {
-        const int n = tile_n * BN + tid * 8;
-        u32x4 b = u32x4{0u, 0u, 0u, 0u};
-        if (p.bias && !p.bias_per_row && n + 8 <= p.n_out) b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
-        *reinterpret_cast<u32x4*>(sBias + tid * 8) = b;
-        if (p.ln_stats) {
-            const float* cs = reinterpret_cast<const float*>(p.ln_colsum) + n;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sCol[tid * 8 + e] = n + e < p.n_out ? cs[e] : 0.0f;
-        }
-    }
     const int ctot = p.c0 + p.c1;
     // split-K: blockIdx.y owns K steps [kbase, kbase + nk) and leaves raw fp32 partial sums in the workspace
     const int nk_all = p.k_pad / BK;
@@ -514,6 +467,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         // SPREAD: the address arithmetic of the NEXT tile to issue (K position, per-row tap offsets) runs at the END of a K
         // step - behind the wave's last MFMAs, in time it would otherwise spend at the barrier - not at its start
         if constexpr (SPREAD) { if (DIST < nk) issue_prepare(DIST, DIST % STAGES); }
+        // the tile's bias slice goes to LDS BEHIND the first operand tiles: its global load would otherwise stall the first
+        // wave for a memory latency before it has issued its DMA share (the K-loop barriers publish the slice)
+        if (tid < BN / 8) {
+            const int n = tile_n * BN + tid * 8;
+            u32x4 b = u32x4{0u, 0u, 0u, 0u};
+            if (p.bias && !p.bias_per_row && n + 8 <= p.n_out) b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
+            *reinterpret_cast<u32x4*>(sBias + tid * 8) = b;
+        }
         for (int kt = 0; kt < nk; ++kt) {
             // tile kt must have landed; the (up to DIST-1) younger tiles may stay in flight
             const int younger = min(nk, kt + DIST) - (kt + 1);
@@ -564,7 +525,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         return;
     }
 
-    cgd_epilogue<T, MI, NI>(p, M, acc, m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN), p.ln_stats ? sCol + wn * (BN / WN) : nullptr);
+    cgd_epilogue<T, MI, NI>(p, M, acc, m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN));
     stamp(5);
 }
 

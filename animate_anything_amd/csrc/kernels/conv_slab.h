@@ -60,13 +60,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv3x3_slab_
     const int tile_m = logical / tiles_n;
     const int tile_n = logical - tile_m * tiles_n;
 
-    if (tid < BN / 8) {
-        const int n = tile_n * BN + tid * 8;
-        u32x4 b = u32x4{0u, 0u, 0u, 0u};
-        if (p.bias && n + 8 <= p.n_out) b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
-        *reinterpret_cast<u32x4*>(sBias + tid * 8) = b;
-    }
-
     const int W = p.w_in, H = p.h_in, WP = W + 2;
     const int m_tile = m_begin + tile_m * BM;                          // first output pixel of the tile
     const int img = m_tile / (H * W);
@@ -151,6 +144,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv3x3_slab_
         static_assert(SJ <= 4, "slab pieces per wave");
         issue_weights(0, 0, 0);
         if (nk > 1) issue_weights(1, 0, 1);
+    }
+    if (tid < BN / 8) {                             // bias slice -> LDS behind the first DMA (published by the K-loop barriers)
+        const int n = tile_n * BN + tid * 8;
+        u32x4 b = u32x4{0u, 0u, 0u, 0u};
+        if (p.bias && n + 8 <= p.n_out) b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
+        *reinterpret_cast<u32x4*>(sBias + tid * 8) = b;
     }
     int u = 0, t = 0, dy = 0, dx = 0;               // unit / tap of step kk
     int u2 = 0, t2 = 2;                             // unit / tap of step kk + 2

@@ -74,37 +74,9 @@ def _no_eager(name):
     raise RuntimeError(f"{name}: this module only runs through the HIP token path of animate_anything_amd")
 
 
-# nn.LayerNorm -> nn.Linear pairs of the big levels run WITHOUT a LayerNorm pass: the producer of the activation emits
-# per-row sums from its epilogue and the consuming linear layer carries gamma / beta in its weights (aa_conv_gemm row_stats_out /
-# ln_stats).  Below this many rows the stand-alone LayerNorm kernel is used (the folded form restricts the producer to
-# 320-column tiles, which under-fills the chip at the 16x16 / 8x8 levels).
-LN_FOLD_MIN_ROWS = 30000
-
-
-def ln_fold_ok(rows, channels):
-    return rows >= LN_FOLD_MIN_ROWS and channels % 160 == 0
-
-
-def new_row_stats(x, channels):
-    return torch.empty(x.shape[0], channels // 160, 2, dtype=torch.float32, device=x.device)
-
-
 class Linear(_Packed, nn.Linear):
-    _pw_ln = None
-    _pw_ln_key = None
-
     def tokens(self, x, **epilogue):
         return ops.conv_gemm(x, self.packed(), ops.linear_geom(x.shape[0]), **epilogue)
-
-    def packed_ln(self, norm):
-        """This layer with the LayerNorm `norm` in front folded in (ops.pack_weight ln_gamma / ln_beta)."""
-        key = weights_key(self.weight, self.bias, norm.weight, norm.bias)
-        if self._pw_ln is None or self._pw_ln_key != key:
-            self._pw_ln, self._pw_ln_key = ops.pack_weight(self.weight, self.bias, ln_gamma=norm.weight, ln_beta=norm.bias), key
-        return self._pw_ln
-
-    def tokens_ln(self, x, norm, stats, **epilogue):
-        return ops.conv_gemm(x, self.packed_ln(norm), ops.linear_geom(x.shape[0]), ln_stats=stats, ln_eps=norm.eps, **epilogue)
 
     def forward(self, x):
         _no_eager("Linear")
@@ -269,8 +241,6 @@ class Attention(nn.Module):
         self.to_out = nn.ModuleList([Linear(inner, query_dim), nn.Dropout(0.0)])
         self._fused = None
         self._fused_key = None
-        self._fused_ln = None
-        self._fused_ln_key = None
         self.kv = None
 
     def _apply(self, fn, *a, **k):
@@ -285,15 +255,6 @@ class Attention(nn.Module):
             self._fused, self._fused_key = ops.pack_weight(torch.cat([r.detach() for r in rows], dim=0)), key
         return self._fused
 
-    def fused_ln(self, norm):
-        """Q|K|V of a self-attention with the LayerNorm in front folded in."""
-        rows = [self.to_q.weight, self.to_k.weight, self.to_v.weight]
-        key = weights_key(*rows, norm.weight, norm.bias)
-        if self._fused_ln is None or self._fused_ln_key != key:
-            self._fused_ln = ops.pack_weight(torch.cat([r.detach() for r in rows], dim=0), None, ln_gamma=norm.weight, ln_beta=norm.bias)
-            self._fused_ln_key = key
-        return self._fused_ln
-
     def text_kv(self, text_tokens):
         """[clips*L, cross_dim] -> [clips*L, 2*inner] (K | V): normally a column slice of ONE projection of the text for
         all cross-attention layers of the network (`kv` set by the UNet per forward)."""
@@ -302,14 +263,8 @@ class Attention(nn.Module):
             return kv
         return ops.conv_gemm(text_tokens, self.fused(), ops.linear_geom(text_tokens.shape[0]))
 
-    def self_tokens(self, x, norm, stats, g: Grid, temporal: bool, out_stats=None):
-        """LayerNorm `norm` -> Q|K|V -> attention -> to_out + x.  `stats`: row statistics of x from its producer (folded
-        LayerNorm) or None (stand-alone LayerNorm kernel); `out_stats`: filled with the row statistics of the result."""
-        if stats is not None:
-            qkv = ops.conv_gemm(x, self.fused_ln(norm), ops.linear_geom(x.shape[0]), ln_stats=stats, ln_eps=norm.eps)
-        else:
-            qkv = ops.conv_gemm(norm.tokens(x), self.fused(), ops.linear_geom(x.shape[0]))
-        residual = x
+    def self_tokens(self, normed, residual, g: Grid, temporal: bool):
+        qkv = ops.conv_gemm(normed, self.fused(), ops.linear_geom(normed.shape[0]))
         c = self.inner
         if temporal:
             st = (g.frames * g.hw, 1, g.hw)
@@ -317,13 +272,13 @@ class Attention(nn.Module):
         else:
             st = (g.hw, 0, 1)
             a = ops.attention(qkv, 0, qkv, c, qkv, 2 * c, self.heads, g.images, 1, g.hw, g.hw, st, st)
-        return self.to_out[0].tokens(a, residual=residual, row_stats=out_stats)
+        return self.to_out[0].tokens(a, residual=residual)
 
-    def cross_tokens(self, x, norm, stats, g: Grid, kv, kv_len, out_stats=None):
-        q = self.to_q.tokens_ln(x, norm, stats) if stats is not None else self.to_q.tokens(norm.tokens(x))
+    def cross_tokens(self, normed, residual, g: Grid, kv, kv_len):
+        q = self.to_q.tokens(normed)
         a = ops.attention(q, 0, kv, 0, kv, self.inner, self.heads, g.images, 1, g.hw, kv_len,
                           (g.hw, 0, 1), (kv_len, 0, 1), kv_outer_div=g.frames)
-        return self.to_out[0].tokens(a, residual=x, row_stats=out_stats)
+        return self.to_out[0].tokens(a, residual=residual)
 
 
 class GEGLU(nn.Module):
@@ -343,17 +298,8 @@ class GEGLU(nn.Module):
             self._pw, self._pw_key = ops.pack_weight(self.proj.weight, self.proj.bias, geglu=True), key
         return self._pw
 
-    def packed_ln(self, norm):
-        key = weights_key(self.proj.weight, self.proj.bias, norm.weight, norm.bias)
-        if getattr(self, "_pw_ln", None) is None or self._pw_ln_key != key:
-            self._pw_ln = ops.pack_weight(self.proj.weight, self.proj.bias, geglu=True, ln_gamma=norm.weight, ln_beta=norm.bias)
-            self._pw_ln_key = key
-        return self._pw_ln
-
-    def tokens(self, x, norm=None, stats=None):
-        if stats is not None:
-            return ops.conv_gemm(x, self.packed_ln(norm), ops.linear_geom(x.shape[0]), ln_stats=stats, ln_eps=norm.eps)
-        return ops.conv_gemm(x if norm is None else norm.tokens(x), self.packed(), ops.linear_geom(x.shape[0]))
+    def tokens(self, x):
+        return ops.conv_gemm(x, self.packed(), ops.linear_geom(x.shape[0]))
 
 
 class FeedForward(nn.Module):
@@ -361,9 +307,8 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim)])
 
-    def tokens(self, x, norm, stats):
-        """LayerNorm `norm` -> GEGLU -> Linear + x."""
-        return self.net[2].tokens(self.net[0].tokens(x, norm, stats), residual=x)
+    def tokens(self, x, residual):
+        return self.net[2].tokens(self.net[0].tokens(x), residual=residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -377,19 +322,14 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.double_self_attention = double_self_attention
 
-    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0, stats=None):
-        """`stats`: row statistics of x emitted by its producer (the proj_in of the enclosing transformer model); when
-        given, none of the three LayerNorms runs as a kernel (see LN_FOLD_MIN_ROWS)."""
-        fold = stats is not None
-        s1 = new_row_stats(x, x.shape[1]) if fold else None
-        x = self.attn1.self_tokens(x, self.norm1, stats, g, temporal, out_stats=s1)
-        s2 = new_row_stats(x, x.shape[1]) if fold else None
+    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0):
+        x = self.attn1.self_tokens(self.norm1.tokens(x), x, g, temporal)
         if self.attn2.is_cross:
             kv = self.attn2.text_kv(text)
-            x = self.attn2.cross_tokens(x, self.norm2, s1, g, kv, text_len, out_stats=s2)
+            x = self.attn2.cross_tokens(self.norm2.tokens(x), x, g, kv, text_len)
         else:
-            x = self.attn2.self_tokens(x, self.norm2, s1, g, temporal, out_stats=s2)
-        return self.ff.tokens(x, self.norm3, s2)
+            x = self.attn2.self_tokens(self.norm2.tokens(x), x, g, temporal)
+        return self.ff.tokens(self.norm3.tokens(x), residual=x)
 
 
 class Transformer2DModel(nn.Module):
@@ -404,12 +344,9 @@ class Transformer2DModel(nn.Module):
         self.proj_out = Linear(inner, in_channels)
 
     def tokens(self, x, g: Grid, text, text_len):
-        inner = self.proj_in.out_features
-        stats = new_row_stats(x, inner) if ln_fold_ok(x.shape[0], inner) else None
-        h = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw), row_stats=stats)
+        h = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw))
         for blk in self.transformer_blocks:
-            h = blk.tokens(h, g, temporal=False, text=text, text_len=text_len, stats=stats)
-            stats = None                                   # (one block per model in this architecture)
+            h = blk.tokens(h, g, temporal=False, text=text, text_len=text_len)
         return self.proj_out.tokens(h, residual=x)
 
 
@@ -427,10 +364,7 @@ class TransformerTemporalModel(nn.Module):
         self.proj_out = Linear(inner, in_channels)
 
     def tokens(self, x, g: Grid):
-        inner = self.proj_in.out_features
-        stats = new_row_stats(x, inner) if ln_fold_ok(x.shape[0], inner) else None
-        h = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw), row_stats=stats)
+        h = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw))
         for blk in self.transformer_blocks:
-            h = blk.tokens(h, g, temporal=True, stats=stats)
-            stats = None
+            h = blk.tokens(h, g, temporal=True)
         return self.proj_out.tokens(h, residual=x)

@@ -220,7 +220,6 @@ class PackedWeight:
     cin: int          # channels per tap as stored (after padding to a multiple of 8)
     geglu: int = 0    # 0, or the value/gate interleave granularity of a GEGLU projection
     k_order: int = 0  # 0: K = (tap, channel); 1: K = (64-channel chunk, tap, channel)
-    ln_colsum: Optional[torch.Tensor] = None   # fp32 [n_pad]: row sums of the LayerNorm-folded weights (see pack_weight)
 
     @property
     def n_pad(self):
@@ -231,28 +230,13 @@ class PackedWeight:
         return self.w.shape[1]
 
 
-def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu: bool = False,
-                ln_gamma: Optional[torch.Tensor] = None, ln_beta: Optional[torch.Tensor] = None) -> PackedWeight:
+def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu: bool = False) -> PackedWeight:
     """Pack an nn.Linear [n,k], nn.Conv2d [n,c,kh,kw] or nn.Conv3d [n,c,kt,1,1] weight.
-
-    `ln_gamma` / `ln_beta` fold the nn.LayerNorm in front of a linear layer into it (aa_conv_gemm `ln_stats`):
-    W' = W diag(gamma), b' = b + W beta, and `ln_colsum[n] = sum_c W'[n][c]` of the ROUNDED W' (what the matrix cores
-    multiply) for the epilogue's  rstd * (acc - mean * colsum) + b'.
 
     GEGLU (diffusers `GEGLU.proj`, rows [0,d) = value, [d,2d) = gate) is re-ordered into alternating
     blocks of 32 value rows / 32 gate rows: a value block and its gate block are then neighbouring accumulator
     blocks of the same wavefront and the gating happens in registers."""
     w = weight.detach()
-    bias = None if bias is None else bias.detach()
-    colsum = None
-    if ln_gamma is not None:
-        assert w.dim() == 2, "LayerNorm folds into linear layers"
-        w32 = w.float()
-        b32 = (bias.float() if bias is not None else torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)) + \
-            w32 @ ln_beta.detach().float()
-        w = (w32 * ln_gamma.detach().float()[None, :]).to(w.dtype)
-        bias = b32.to(w.dtype)
-        colsum = w.float().sum(dim=1)
     if w.dim() == 2:
         n, kh, kw, cin = w.shape[0], 1, 1, w.shape[1]
         w4 = w.reshape(n, 1, 1, cin)
@@ -284,16 +268,12 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
         src = torch.cat([val, val + d], dim=1).reshape(-1)
         w2 = w2[src]
         b = None if b is None else b[src]
-        colsum = None if colsum is None else colsum[src]
     n_pad, k_pad = _round_up(n, 64), _round_up(k, 64)
     out = torch.zeros(n_pad, k_pad, dtype=w.dtype, device=w.device)
     out[:n, :k] = w2
     if b is not None and geglu and n_pad != n:
         b = torch.nn.functional.pad(b, (0, n_pad - n))
-    if colsum is not None:
-        colsum = torch.nn.functional.pad(colsum, (0, n_pad - n)).contiguous()
-    return PackedWeight(out.contiguous(), None if b is None else b.contiguous(), n, kh, kw, cpad, gran if geglu else 0, k_order,
-                        colsum)
+    return PackedWeight(out.contiguous(), None if b is None else b.contiguous(), n, kh, kw, cpad, gran if geglu else 0, k_order)
 
 
 # ------------------------------------------------------------------------------------- contraction
@@ -343,10 +323,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
               rowvec: Optional[torch.Tensor] = None, rowvec_div: int = 1,
               residual: Optional[torch.Tensor] = None, act: int = AA_ACT_NONE, out_dtype=None,
               out_scale: float = 1.0, bias_per_row: bool = False, out: Optional[torch.Tensor] = None,
-              bias: Optional[torch.Tensor] = "packed", row_stats: Optional[torch.Tensor] = None,
-              ln_stats: Optional[torch.Tensor] = None, ln_eps: float = 1e-5) -> torch.Tensor:
-    """`row_stats`: fp32 [rows, n_out // 160, 2] to fill with the per-row chunk sums of the output (producer of a folded
-    LayerNorm); `ln_stats`: such a tensor describing x0's rows, with `pw` packed by pack_weight(ln_gamma=, ln_beta=)."""
+              bias: Optional[torch.Tensor] = "packed") -> torch.Tensor:
     lib = _lib.get()
     b = pw.bias if isinstance(bias, str) else bias
     _check(x0, x1, pw.w, b, residual, out)
@@ -361,7 +338,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     in_rows = g.n_img * g.h_in * g.w_in
     biggest = 2 * max(in_rows * max(c0, c1), g.rows * max(n_cols_ if out is None else out.stride(0),
                                                           0 if residual is None else residual.stride(0)))
-    if biggest >= MAX_OPERAND_BYTES and g.n_img > 1 and not bias_per_row and row_stats is None and ln_stats is None:
+    if biggest >= MAX_OPERAND_BYTES and g.n_img > 1 and not bias_per_row:
         if out is None:
             out = torch.empty(g.rows, n_cols_, dtype=x0.dtype if out_dtype is None else out_dtype, device=x0.device)
         parts = min(g.n_img, -(-biggest // (MAX_OPERAND_BYTES // 2)))
@@ -400,17 +377,11 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.act, d.geglu, d.bias_per_row = act, int(pw.geglu), int(bias_per_row)
     d.dtype, d.out_dtype, d.out_scale = _DT[x0.dtype], _DT[odt], out_scale
     d.k_order = pw.k_order
-    if row_stats is not None:
-        assert row_stats.dtype == torch.float32 and row_stats.is_contiguous() and row_stats.shape == (g.rows, pw.n_out // 160, 2)
-        d.row_stats_out = _ptr(row_stats)
-    if ln_stats is not None:
-        assert pw.ln_colsum is not None and ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.shape[0] == g.rows
-        d.ln_stats, d.ln_colsum, d.ln_chunks, d.ln_eps = _ptr(ln_stats), _ptr(pw.ln_colsum), ln_stats.shape[1], ln_eps
     d.debug = DEBUG_ABLATE
     d.tile, d.k_splits = -1, K_SPLITS
     if AUTOTUNE and x0.is_cuda:
         key = (d.dtype, g.n_img, g.h_in, g.w_in, d.h_virt, d.w_virt, g.h_out, g.w_out, g.stride, pw.kh, pw.kw, c0, c1,
-               pw.n_out, d.geglu, residual is not None, row_stats is not None, ln_stats is not None)
+               pw.n_out, d.geglu, residual is not None)
         _load_default_tile_cache()
         choice = _tile_cache.get(key)
         # the tuning launches write `out` repeatedly: only safe when no input of the call aliases it
@@ -430,7 +401,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
         d.workspace, d.workspace_bytes = _ptr(ws), need
     _run(lib.aa_conv_gemm, C.byref(d), _stream(x0))
     if TRACE is not None:
-        TRACE.append((d, (x0, x1, pw, b, rowvec, residual, out, ws, row_stats, ln_stats)))
+        TRACE.append((d, (x0, x1, pw, b, rowvec, residual, out, ws)))
     return out
 
 

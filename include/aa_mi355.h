@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AA_VERSION 102
+#define AA_VERSION 101
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
@@ -93,20 +93,6 @@ typedef struct AaConvGemm {
     int32_t k_splits;      /* 0: library decides whether to split K; >= 1: this many K ranges (needs the workspace
                               aa_conv_gemm_workspace reports for the same descriptor; ignored when not applicable) */
     int32_t rowvec_ld;     /* row pitch of `rowvec` in elements (a slice of a wider matrix); 0 = n_out */
-    /* ---- version 102: nn.LayerNorm folded into the linear layer that consumes it (diffusers BasicTransformerBlock:
-     * norm1 -> to_q/k/v, norm2 -> to_q, norm3 -> GEGLU), no pass over the tensor for the norm itself.
-     *   producer call:  row_stats_out != NULL  -> besides `out`, writes fp32 [M][n_out/160][2] = (sum, sum of squares) of the
-     *                   STORED values of every 160-column chunk of each output row (needs n_out % 160 == 0, no GEGLU; the
-     *                   library then only uses its 320-column tiles);
-     *   consumer call:  ln_stats != NULL       -> `w` / `bias` were folded by the host (W' = W diag(gamma), b' = b + W beta),
-     *                   ln_colsum[n] = sum_c W'[n][c] (fp32, n_pad entries), ln_stats = the producer's row_stats_out with
-     *                   ln_chunks chunks per row; the epilogue applies  rstd_r (acc - mean_r ln_colsum[n]) + b'[n]
-     *                   in front of the activation / GEGLU / residual. */
-    void* row_stats_out;
-    const void* ln_stats;
-    const void* ln_colsum;
-    int32_t ln_chunks;
-    float ln_eps;
 } AaConvGemm;
 
 /* Bytes of fp32 scratch with which aa_conv_gemm would split the K loop of this call over several workgroups

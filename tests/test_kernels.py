@@ -533,27 +533,3 @@ def test_halo_slab_eligibility(emu):
     assert lib.aa_conv_gemm_tile_ok(C.byref(d), 34) == 0
     d.stride, d.h_in, d.w_in, d.h_virt, d.w_virt, d.h_out, d.w_out = 1, 55, 74, 55, 74, 55, 74                  # irregular eval size
     assert lib.aa_conv_gemm_tile_ok(C.byref(d), 34) == 0 and lib.aa_conv_gemm_tile_ok(C.byref(d), 14) == 1
-
-
-@pytest.mark.parametrize("M,C,N,geglu", [(300, 320, 960, False), (260, 640, 320, False), (200, 320, 640, True)])
-def test_layernorm_folded_into_linear(backend, M, C, N, geglu):
-    """nn.LayerNorm -> nn.Linear without a LayerNorm pass: the producer GEMM (+residual) emits per-row chunk sums of its
-    stored output, the consumer GEMM carries gamma / beta in its weights and normalises in the epilogue; checked against
-    F.layer_norm + F.linear (+GEGLU) on the producer's stored output, incl. rows with a large mean."""
-    K0 = 128
-    a, w0, b0 = rnd(M, K0, seed=191), rnd(C, K0, scale=0.1, seed=192), rnd(C, seed=193)
-    res = rnd(M, C, seed=194)
-    res[:, :] += torch.linspace(-6, 6, M, dtype=torch.float32)[:, None].to(DT).to(DEV)      # per-row offsets: means far from zero
-    stats = torch.zeros(M, C // 160, 2, dtype=torch.float32, device=DEV)
-    x = ops.conv_gemm(a, ops.pack_weight(w0, b0), ops.linear_geom(M), residual=res, row_stats=stats)
-    xf = x.float().cpu()
-    want_stats = torch.stack([xf.reshape(M, C // 160, 160).sum(-1), (xf ** 2).reshape(M, C // 160, 160).sum(-1)], dim=-1)
-    close(stats, want_stats, tol=1e-4)
-    gamma, beta = rnd(C, seed=195) * 0.5 + 1.0, rnd(C, scale=0.3, seed=196)
-    w1, b1 = rnd(N, C, scale=0.05, seed=197), rnd(N, seed=198)
-    y = ops.conv_gemm(x, ops.pack_weight(w1, b1, geglu=geglu, ln_gamma=gamma, ln_beta=beta), ops.linear_geom(M), ln_stats=stats, ln_eps=1e-5)
-    ln = F.layer_norm(xf, (C,), gamma.float().cpu(), beta.float().cpu(), 1e-5)
-    ref = ln @ w1.float().cpu().t() + b1.float().cpu()
-    if geglu:
-        ref = ref[:, :N // 2] * F.gelu(ref[:, N // 2:])
-    close(y, ref, tol=2e-2)
