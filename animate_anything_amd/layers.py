@@ -322,8 +322,14 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.double_self_attention = double_self_attention
 
-    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0):
+    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0, dup: int = 1):
+        """`dup` > 1: x holds ONE copy of `dup` identical groups of clips (classifier-free guidance runs the same latents
+        with two prompts, models/pipeline.py:165): the self-attention - which never sees the text - is computed once and
+        its result replicated in front of the cross-attention; `g` describes the single copy."""
         x = self.attn1.self_tokens(self.norm1.tokens(x), x, g, temporal)
+        if dup > 1:
+            x = torch.cat([x] * dup)
+            g = replace(g, clips=g.clips * dup)
         if self.attn2.is_cross:
             kv = self.attn2.text_kv(text)
             x = self.attn2.cross_tokens(self.norm2.tokens(x), x, g, kv, text_len)
@@ -343,11 +349,14 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, head_dim, cross_attention_dim)])
         self.proj_out = Linear(inner, in_channels)
 
-    def tokens(self, x, g: Grid, text, text_len):
+    def tokens(self, x, g: Grid, text, text_len, dup: int = 1):
+        """`dup` > 1 (see BasicTransformerBlock.tokens): x / g are the single copy, the result covers all `dup` groups."""
         h = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw))
-        for blk in self.transformer_blocks:
-            h = blk.tokens(h, g, temporal=False, text=text, text_len=text_len)
-        return self.proj_out.tokens(h, residual=x)
+        for i, blk in enumerate(self.transformer_blocks):
+            h = blk.tokens(h, g, temporal=False, text=text, text_len=text_len, dup=dup if i == 0 else 1)
+            if i == 0 and dup > 1:
+                g = replace(g, clips=g.clips * dup)
+        return self.proj_out.tokens(h, residual=torch.cat([x] * dup) if dup > 1 else x)
 
 
 class TransformerTemporalModel(nn.Module):

@@ -57,6 +57,8 @@ def tensor2vid(video):
 
 
 class LatentToVideoPipeline:
+    cfg_shared_prefix = True     # compute the text-independent prefix of the UNet once per guidance pair (identical results)
+
     def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet=None, scheduler=None):
         self.vae, self.text_encoder, self.tokenizer, self.unet = vae, text_encoder, tokenizer, unet
         self.scheduler = scheduler if scheduler is not None else DPMSolverMultistepScheduler()
@@ -154,8 +156,11 @@ class LatentToVideoPipeline:
         b = 2 * b0 if cfg else b0
         use_mask = bool(unet.motion_mask and mask is not None)
         has_motion = bool(unet.motion_strength and motion is not None)
+        # under guidance both halves of the UNet batch see the same latents / condition frame / mask / timestep / motion and
+        # differ only in the text: the UNet computes the text-independent prefix once (UNet3DConditionModel._core cfg_dup)
+        shared = cfg and self.cfg_shared_prefix and b0 % condition_latent.shape[0] == 0 and (not use_mask or b0 % mask.shape[0] == 0)
         sess = unet.session(b, frames, h, w, tuple(prompt_embeds.shape[1:]), use_mask, has_motion, False, torch.float32, b0,
-                            condition_latent.shape[0], mask.shape[0] if use_mask else 0, dev)
+                            condition_latent.shape[0], mask.shape[0] if use_mask else 0, dev, cfg_dup=shared)
         mot = None
         if has_motion:
             mot = torch.as_tensor(motion, device=dev).to(torch.float32).reshape(-1).expand(b).contiguous()

@@ -50,22 +50,28 @@ class _Stage(nn.Module):
         self.downsamplers = nn.ModuleList([Downsample2D(out_ch, out_ch, padding=down)]) if down is not None else None
         self.upsamplers = nn.ModuleList([Upsample2D(out_ch, out_ch)]) if up else None
 
-    def _layer(self, i, x, g, temb_silu, text, text_len, skip=None):
+    def _layer(self, i, x, g, temb_silu, text, text_len, skip=None, dup=1):
+        """`dup` > 1: x / g hold one copy of `dup` identical groups of clips (guidance); everything in front of the first
+        text cross-attention is computed once, the result covers all groups."""
         x = self.resnets[i].tokens(x, g, temb_silu, x1=skip)
         if g.frames > 1:
             x = self.temp_convs[i].tokens(x, g)
         if self.has_cross_attention:
-            x = self.attentions[i].tokens(x, g, text, text_len)
+            x = self.attentions[i].tokens(x, g, text, text_len, dup=dup)
+            if dup > 1:
+                g = Grid(g.clips * dup, g.frames, g.h, g.w)
             if g.frames > 1:
                 x = self.temp_attentions[i].tokens(x, g)
         return x
 
 
 class _DownStage(_Stage):
-    def tokens(self, x, g, temb_silu, text, text_len):
+    def tokens(self, x, g, temb_silu, text, text_len, dup=1):
         outs = []
         for i in range(len(self.resnets)):
-            x = self._layer(i, x, g, temb_silu, text, text_len)
+            x = self._layer(i, x, g, temb_silu, text, text_len, dup=dup if i == 0 else 1)
+            if i == 0 and dup > 1:
+                g = Grid(g.clips * dup, g.frames, g.h, g.w)
             outs.append((x, g))
         if self.downsamplers is not None:
             x, g = self.downsamplers[0].tokens(x, g)
@@ -330,25 +336,37 @@ class UNet3DConditionModel(nn.Module):
                   os.path.join(path, "diffusion_pytorch_model.safetensors"))
 
     # ------------------------------------------------------------------ hot path
-    def _core(self, sample, cond, mask, t, motion_t, cond_emb, text_tokens, g: Grid, text_len: int, upsample_sizes):
+    def _core(self, sample, cond, mask, t, motion_t, cond_emb, text_tokens, g: Grid, text_len: int, upsample_sizes, cfg_dup=False):
         """Everything between the boundary tensors: only libaa_mi355 launches (graph-capturable).
+        `cfg_dup`: the caller guarantees that the two halves of the batch differ ONLY in the text (classifier-free guidance,
+        models/pipeline.py:160-168: same latents, condition frame, mask, timestep and motion for the unconditional and the
+        text half).  Everything the text cannot reach - conv_in, transformer_in, the first resnet / temporal conv and the
+        first spatial self-attention - is then computed for ONE half and replicated in front of the first text
+        cross-attention: identical results, the redundant half of that prefix is not recomputed.
         sample [Bs,C,T,h,w] (fp32 or storage dtype), cond [Bc,C,1,h,w], mask [Bm,1,1,h,w] | None, t fp32 [B], motion_t fp32 [B] |
         None (or a ready [B, ch0] `cond_emb`), text_tokens [B*L, D]; returns [B*(T+1)*h*w, out_channels] tokens."""
         dt = text_tokens.dtype
         ch0 = self.conv_in.out_channels
         t_sin = ops.timestep_embedding(t, ch0, dt)                                       # :408-413
         cond_sin = ops.timestep_embedding(motion_t, ch0, dt) if motion_t is not None else cond_emb   # :414-416
-        x8 = ops.pack_latents(sample, cond, mask, g.clips, dt)                            # :376, :424-428
+        dup = 2 if (cfg_dup and g.clips % 2 == 0 and self.down_blocks[0].has_cross_attention) else 1
+        g0 = Grid(g.clips // dup, g.frames, g.h, g.w)
+        x8 = ops.pack_latents(sample, cond, mask, g0.clips, dt)                           # :376, :424-428
         temb_silu = self.time_embedding.tokens(t_sin, cond_sin, final_silu=True)       # [clips, 4*ch0]
         self._project_time_embeddings(temb_silu)
         self._project_text(text_tokens)
         conv_in = self.conv_in2 if mask is not None else self.conv_in
-        x = conv_in.tokens(x8, ops.conv3x3_geom(g.images, g.h, g.w))
+        x = conv_in.tokens(x8, ops.conv3x3_geom(g0.images, g0.h, g0.w))
         if g.frames > 1:
-            x = self.transformer_in.tokens(x, g)
-        skips = [(x, g)]
-        for blk in self.down_blocks:
-            x, g, outs = blk.tokens(x, g, temb_silu, text_tokens, text_len)
+            x = self.transformer_in.tokens(x, g0)
+        skips = [(torch.cat([x] * dup) if dup > 1 else x, g)]
+        for i, blk in enumerate(self.down_blocks):
+            if i == 0:
+                x, _, outs = blk.tokens(x, g0, temb_silu, text_tokens, text_len, dup=dup)
+            else:
+                x, g, outs = blk.tokens(x, g, temb_silu, text_tokens, text_len)
+            if i == 0:
+                g = outs[-1][1]
             skips += outs
         x = self.mid_block.tokens(x, g, temb_silu, text_tokens, text_len)
         for i, blk in enumerate(self.up_blocks):
@@ -396,12 +414,12 @@ class UNet3DConditionModel(nn.Module):
         self._graph = {} if enabled else None
 
     def session(self, batch, frames, h, w, text_shape, use_mask, has_motion, has_cond_emb, sample_dtype, sample_batch,
-                cond_batch, mask_batch, device):
+                cond_batch, mask_batch, device, cfg_dup=False):
         """The static input buffers (and, when graphs are enabled, the captured hipGraph) of one input signature.
         A caller that owns the denoising loop (LatentToVideoPipeline.denoise) writes its inputs straight into
         `sess.inputs[...]` once and then only calls `sess.run()` per step."""
         key = (batch, frames, h, w, tuple(text_shape), use_mask, has_motion, has_cond_emb, sample_dtype, sample_batch,
-               cond_batch, mask_batch, self.dtype, str(device))
+               cond_batch, mask_batch, self.dtype, str(device), bool(cfg_dup))
         store = self._graph if self._graph is not None else self.__dict__.setdefault("_eager_sessions", {})
         sess = store.get(key)
         if sess is None:
@@ -414,7 +432,7 @@ class UNet3DConditionModel(nn.Module):
 class _Session:
     def __init__(self, net, key, device):
         (b, frames, h, w, text_shape, use_mask, has_motion, has_cond_emb, sample_dtype, sample_batch, cond_batch, mask_batch,
-         dt, _dev) = key
+         dt, _dev, self.cfg_dup) = key
         self.net, self.b, self.frames, self.h, self.w = net, b, frames, h, w
         z = lambda *s, dtype=dt: torch.zeros(*s, dtype=dtype, device=device)
         c = net.config.in_channels
@@ -447,7 +465,8 @@ class _Session:
     def _core(self):
         i = self.inputs
         return self.net._core(i["sample"], i["cond"], i["mask"], i["t"], i["motion"], i["cond_emb"],
-                              i["text"].reshape(-1, i["text"].shape[-1]), self.grid, self.text_len, self.upsample_sizes)
+                              i["text"].reshape(-1, i["text"].shape[-1]), self.grid, self.text_len, self.upsample_sizes,
+                              cfg_dup=self.cfg_dup)
 
     def run(self):
         if self.net._graph is None:

@@ -42,6 +42,9 @@ def parse():
     p.add_argument("--frames", type=int, default=16)
     p.add_argument("--size", type=int, default=512)
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--cfg-shared-prefix", action="store_true",
+                   help="time the product default (text-independent UNet prefix computed once per guidance pair) as the headline "
+                        "instead of the strict form that recomputes it for both halves like the reference")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-tile-cache", action="store_true", help="ignore the committed tile choices (animate_anything_amd/tile_cache_gfx950.json): autotune everything")
@@ -173,6 +176,11 @@ def main():
     if a.tile_cache and os.path.exists(a.tile_cache):
         ops.load_tile_cache(a.tile_cache)
 
+    # Headline = the STRICT step: both guidance halves run the whole UNet, as the reference does (44.262 TFLOP).  The product's
+    # default computes the text-independent prefix once per pair (identical latents, 1.64 TFLOP less): timed too, reported
+    # separately as `cfg_shared_prefix` (or as the headline with --cfg-shared-prefix).
+    pipe.cfg_shared_prefix = bool(a.cfg_shared_prefix)
+
     def run(tsteps, x):
         return pipe.denoise(x, embeds, inp["cond"], inp["mask"], [3.0], tsteps, 9.0)
 
@@ -200,6 +208,28 @@ def main():
     assert gathered.shape[0] == num_clips
     assert torch.isfinite(x).all() and torch.isfinite(gathered).all(), "non-finite latents"
 
+    # the other form of the step (shared prefix on <-> off), same number of steps, same protocol
+    other = None
+    if True:
+        pipe.cfg_shared_prefix = not a.cfg_shared_prefix
+        with torch.no_grad():
+            xo = run(ts[: max(a.warmup, 1)], inp["latents"])
+            barrier()
+            t1 = time.perf_counter()
+            xo = run(ts[a.warmup:], xo)
+            barrier()
+            dto = time.perf_counter() - t1
+        if world > 1:
+            tmx = torch.tensor([dto], device=device)
+            dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+            dto = tmx.item()
+        other = {"cfg_shared_prefix": not a.cfg_shared_prefix, "value": round(world * a.steps / dto, 4), "ms_per_step": round(dto / a.steps * 1e3, 3),
+                 "note": "same step with the text-independent UNet prefix (conv_in, transformer_in, first resnet / temporal conv / spatial "
+                         "self-attention) computed once per guidance pair instead of twice: identical latents, 42.621 instead of 44.262 TFLOP executed"}
+        pipe.cfg_shared_prefix = bool(a.cfg_shared_prefix)
+        max_diff = (xo.float() - x.float()).abs().max().item()
+        other["max_abs_latent_difference_vs_headline_run"] = max_diff
+    flop_step = FLOP_PER_STEP - (1.641e12 if a.cfg_shared_prefix else 0.0)
     ms_step = dt / a.steps * 1e3
     value = world * a.steps / dt
     out = {
@@ -212,7 +242,8 @@ def main():
                    "clips_per_gpu": 1, "clips": num_clips, "parallelism": f"clip-sharded x{world}",
                    "collective": "none in the data path; one all_gather_into_tensor of the final latents (RCCL)" if world > 1 else "none"},
         "per_rank_ms_per_step": per_rank_ms,
-        "tflops_per_gpu": round(FLOP_PER_STEP * (a.steps / dt) / 1e12 * (a.frames + 1) / 17 * (lat / 64) ** 2, 2),
+        "tflops_per_gpu": round(flop_step * (a.steps / dt) / 1e12 * (a.frames + 1) / 17 * (lat / 64) ** 2, 2),
+        "flop_per_step_executed": flop_step, "cfg_shared_prefix": bool(a.cfg_shared_prefix), "other_form": other,
     }
 
     if rank == 0 and not a.no_roofline:
@@ -280,7 +311,7 @@ def main():
                            "kernel": "aa::conv_gemm_dma_kernel (LDS-DMA implicit-GEMM conv/linear, all instances)",
                            "launches_per_step": len(trace), "avg_launch_us": round(gemm_ms * 1e3 / len(trace), 2),
                            "flop_per_step_in_kernel": flops, "kernel_ms_per_step": round(gemm_ms, 3),
-                           "whole_step_frac_of_peak": round(FLOP_PER_STEP * (a.steps / dt) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                           "whole_step_frac_of_peak": round(flop_step * (a.steps / dt) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -64,3 +64,29 @@ def seeded_state_other(module):
     g = torch.Generator().manual_seed(77)
     return {k: (torch.randn(v.shape, generator=g) * (0.05 if v.dim() > 1 else 0.3) + (1.0 if "norm" in k and k.endswith("weight") else 0.0))
             for k, v in module.state_dict().items()}
+
+
+def test_cfg_shared_prefix_matches_full_batch(emu):
+    """Under guidance the text-independent prefix of the UNet (conv_in ... first spatial self-attention) is computed for one
+    half of the batch and replicated (UNet3DConditionModel._core cfg_dup): same latents as running both halves in full."""
+    from animate_anything_amd.pipeline import LatentToVideoPipeline
+    from animate_anything_amd.schedulers import DPMSolverMultistepScheduler
+    torch.manual_seed(0)
+    net = UNet3DConditionModel(**TINY_UNET).eval()
+    net.load_state_dict(seeded_state(oracle.UNet3DConditionModel(**TINY_UNET)))
+    net = net.half()
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g)
+    lat, cond, pos, neg = r(1, 4, 2, 5, 6), r(1, 4, 1, 5, 6), r(1, 9, 64), r(1, 9, 64)
+    mask = torch.zeros(1, 1, 1, 5, 6)
+    mask[..., 1:4, 2:5] = 1
+    outs = []
+    for shared in (True, False):
+        pipe = LatentToVideoPipeline(vae=None, unet=net, scheduler=DPMSolverMultistepScheduler())
+        pipe.cfg_shared_prefix = shared
+        pipe.scheduler.set_timesteps(2)
+        with torch.no_grad():
+            outs.append(pipe.denoise(lat, torch.cat([neg, pos]).half(), cond.half(), mask.half(), [3.0],
+                                     [int(t) for t in pipe.scheduler.timesteps], 9.0))
+    assert torch.isfinite(outs[0]).all()
+    assert rel_err(outs[0], outs[1]) < 2e-3
