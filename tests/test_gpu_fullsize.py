@@ -246,3 +246,33 @@ def test_full_size_vae_decode_and_encode_one_frame():
         want_z = ref.encode(img).latent_dist.mode()
         got_z = vae.encode(img.half().cuda()).latent_dist.mode()
         assert rel_err(got_z, want_z) < 2e-2
+
+
+def test_cfg_shared_prefix_equals_full_batch_at_the_metric_configuration():
+    """LatentToVideoPipeline.denoise under guidance computes the text-independent UNet prefix once per pair: ONE full-size
+    step both ways (same seeded weights / inputs as bench.py) must give the same latents to fp16 rounding."""
+    from animate_anything_amd.pipeline import LatentToVideoPipeline
+    from animate_anything_amd.schedulers import DPMSolverMultistepScheduler
+    from animate_anything_amd.unet3d import UNet3DConditionModel
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        net = UNet3DConditionModel(**FULL_UNET)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            if p_.abs().max() == 0:
+                p_.normal_(0.0, 0.02)
+    net = net.to(DT).eval()
+    i = fullsize_inputs(16, 64)
+    lat = i["sample"][:1].cuda().float()
+    outs = []
+    for shared in (False, True):
+        pipe = LatentToVideoPipeline(vae=None, unet=net, scheduler=DPMSolverMultistepScheduler())
+        pipe.cfg_shared_prefix = shared
+        pipe.scheduler.set_timesteps(25)
+        ts = [int(t) for t in pipe.scheduler.timesteps][:2]
+        with torch.no_grad():
+            outs.append(pipe.denoise(lat, i["text"].to(DT).cuda(), i["cond"][:1].to(DT).cuda(), i["mask"].to(DT).cuda(), [3.0], ts, 9.0))
+    a, b = outs[0].float(), outs[1].float()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    err = (a - b).abs().max().item()
+    assert err < 2e-2 * max(1.0, a.abs().max().item()), (err, a.abs().max().item())
