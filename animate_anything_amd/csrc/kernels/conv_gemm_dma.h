@@ -70,7 +70,7 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
                 const T* src = pre_is_rv ? rv + n_rv : rs + n_rs;
                 pre[j][q] = ok ? *reinterpret_cast<const u32x4*>(src) : AA_ZERO4;
             }
-        auto finish_block = [&](int j, Pack8<T> (&o)[2]) __attribute__((always_inline)) {   // residual / scale and the two stores of one 32x32 block
+        auto finish_block = [&](int j, float (&v)[2][8]) __attribute__((always_inline)) {   // residual / scale in fp32, ONE rounding, the two stores of a 32x32 block
             const int nc = col_of(j);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -79,9 +79,12 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
                     Pack8<T> r; r.raw = AA_ZERO4;
                     if (rs) { if (pre_is_rv) { if (nc + 8 * q + 8 <= n_cols) r.raw = *reinterpret_cast<const u32x4*>(rs + nc + 8 * q); } else r.raw = pv; }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[q].e[e] = (T)(((float)o[q].e[e] + (float)r.e[e]) * p.out_scale);
+                    for (int e = 0; e < 8; ++e) v[q][e] = (v[q][e] + (float)r.e[e]) * p.out_scale;
                 }
-                if (m_ok && nc + 8 * q + 8 <= n_cols) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o[q].raw;
+                Pack8<T> o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.e[e] = (T)v[q][e];
+                if (m_ok && nc + 8 * q + 8 <= n_cols) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o.raw;
             }
         };
         auto block_f32 = [&](int j, float (&v)[2][8]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU) in fp32
@@ -103,14 +106,6 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
                 }
             }
         };
-        auto block_vals = [&](int j, Pack8<T> (&o)[2]) __attribute__((always_inline)) {     // ... rounded to the storage type
-            float v[2][8];
-            block_f32(j, v);
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[q].e[e] = (T)v[q][e];
-        };
         if (p.geglu) {
             if constexpr (NI % 2 == 0) {
 #pragma unroll
@@ -119,20 +114,19 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
                     float val[2][8], gate[2][8];
                     block_f32(j, val);
                     block_f32(j + 1, gate);
-                    Pack8<T> h[2];
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) h[q].e[e] = (T)(val[q][e] * gelu_erf_f(gate[q][e]));
-                    finish_block(j, h);
+                        for (int e = 0; e < 8; ++e) val[q][e] *= gelu_erf_f(gate[q][e]);
+                    finish_block(j, val);
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                Pack8<T> o[2];
-                block_vals(j, o);
-                finish_block(j, o);
+                float v[2][8];
+                block_f32(j, v);
+                finish_block(j, v);
             }
         }
     }
@@ -570,9 +564,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const AaConvGemm p, 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)(T)v[e];            // same rounding point as the fused epilogue
-        if (resid) {
+        if (resid) {                                                 // (fp32 until the single final rounding, like the fused epilogue)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)resid[(int64_t)m * p.ldr + n + e];
         }
