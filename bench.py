@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--frames", type=int, default=16)
     p.add_argument("--size", type=int, default=512)
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-other-form", action="store_true", help="skip the second timing (other guidance form) and the 2-step cross-check: profiling runs")
     p.add_argument("--cfg-shared-prefix", action="store_true",
                    help="time the product default (text-independent UNet prefix computed once per guidance pair) as the headline "
                         "instead of the strict form that recomputes it for both halves like the reference")
@@ -210,7 +211,7 @@ def main():
 
     # the other form of the step (shared prefix on <-> off), same number of steps, same protocol
     other = None
-    if True:
+    if not a.no_other_form:
         pipe.cfg_shared_prefix = not a.cfg_shared_prefix
         with torch.no_grad():
             xo = run(ts[: max(a.warmup, 1)], inp["latents"])
@@ -307,7 +308,7 @@ def main():
         # separate rocprofv3 passes, scripts/pmc_traffic.sh) committed under profiles/ - bench.py cannot run the
         # profiler on itself, so `traffic` is the last committed measurement of the same command (null if absent)
         traffic, tname = None, None
-        for tname_ in ("r02_traffic_pmc.json", "r01_traffic_pmc.json"):
+        for tname_ in ("r02_traffic_pmc.json", "r01_traffic_pmc.json"):     # newest committed PMC measurement of this command
             tpath = os.path.join(ROOT, "profiles", tname_)
             if os.path.exists(tpath):
                 traffic, tname = json.load(open(tpath)).get("conv_gemm_dma_kernel", {}).get("hbm_bytes_per_launch"), tname_
