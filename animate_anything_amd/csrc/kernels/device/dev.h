@@ -42,22 +42,10 @@ __device__ __forceinline__ float wave_sum_halves(float x) {
 // Shader-clock timestamp (s_memtime) for the phase probe (AaConvGemm.debug bit 8).
 __device__ __forceinline__ long long clock_now() { return (long long)__builtin_amdgcn_s_memtime(); }
 
-__device__ __forceinline__ void idle_a_while() { __builtin_amdgcn_s_sleep(8); }
-
-// 64 zero bytes in device memory: what halo / tail lanes of an LDS-DMA tile load read instead of an activation.
-__device__ __attribute__((aligned(64))) u32x4 aa_zero_page_[4];
-__device__ __forceinline__ const void* zero_page() { return aa_zero_page_; }
-
-// LDS-DMA: every lane fetches 16 bytes from its own global address; the wave's 64 pieces land lane-linear
-// at lds_wave_base + lane*16 (wave-uniform base) without passing through VGPRs (global_load_lds_dwordx4).
-// Completion is tracked by vmcnt; a following __syncthreads() drains it.
-__device__ __forceinline__ void async_copy16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// The same through a buffer descriptor: wave-uniform base + range (SGPRs) and one 32-bit byte offset per lane; a lane
-// whose offset is out of range deposits 16 zero bytes (buffer_load_dwordx4 ... offen lds).
+// LDS-DMA through a buffer descriptor: every lane fetches 16 bytes, the wave's 64 pieces land lane-linear at
+// lds_wave_base + lane*16 (wave-uniform base) without passing through VGPRs; operand base + range sit in SGPRs, each lane
+// supplies one 32-bit byte offset, and a lane whose offset is out of range deposits 16 zero bytes
+// (buffer_load_dwordx4 ... offen lds).  Completion is tracked by vmcnt.
 struct BufRsrc { __amdgpu_buffer_rsrc_t v; };
 __device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) {
     return BufRsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000)};
@@ -83,15 +71,6 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" 
 // Workgroup barrier WITHOUT the implicit vmcnt(0) drain of __syncthreads(); the "memory" clobber keeps the
 // compiler from moving LDS / DMA accesses across it.
 __device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "memory"); }
-
-// Scheduling directive for one k sub-step of a fragment-double-buffered MFMA loop: emit the NR ds_reads
-// (next sub-step's fragments) first, then the NM MFMAs of this sub-step - hipcc otherwise sinks the reads
-// next to their first use and waits lgkmcnt(0) right behind them (LDS latency exposed every sub-step).
-template <int NR, int NM>
-__device__ __forceinline__ void sched_reads_then_mfma() {
-    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);   // DS read
-    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);   // MFMA
-}
 
 // Hand-issued LDS fragment read: `dst` is written asynchronously (lgkmcnt); hipcc neither counts it nor waits
 // for it, so every consumer must sit behind lds_wait<N>() / lds_pin() naming the register (cdna guide 5.7).

@@ -220,13 +220,7 @@ inline f32x16 emu_mfma_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
 inline f32x16 mfma_32x32x16(f16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<f16_t>(a, b, c); }
 inline f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<bf16_t>(a, b, c); }
 
-inline void idle_a_while() {}
 inline long long clock_now() { static thread_local long long t = 0; return t += 64; }
-inline const void* zero_page() { static const u32x4 z[4] = {}; return z; }
-inline void async_copy16(const void* gsrc, void* lds_wave_base) {
-    std::memcpy(static_cast<char*>(lds_wave_base) + (emu::linear_tid() & 63) * 16, gsrc, 16);
-}
-
 struct BufRsrc { const char* base; unsigned bytes; };
 inline BufRsrc make_rsrc(const void* base, unsigned bytes) { return BufRsrc{static_cast<const char*>(base), bytes}; }
 inline void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_wave_base) {
@@ -253,9 +247,6 @@ inline u32x2 lds_read_tr16_b64(const void* lds_ptr) {
 template <int N>
 inline void dma_wait() {}                       // the emulator's DMA is synchronous
 inline void block_barrier() { emu::block_barrier(); }
-
-template <int NR, int NM>
-inline void sched_reads_then_mfma() {}
 
 inline void lds_read16_async(u32x4& dst, const void* lds_ptr) { dst = *reinterpret_cast<const u32x4*>(lds_ptr); }
 template <int N>
