@@ -83,3 +83,46 @@ def test_eval_driver_roundtrip(tmp_path):
         timesteps=osched.timesteps)
     mse = ((latents.float().cpu() - want) ** 2).mean().item()
     assert mse < 1e-3, mse
+
+
+def test_stage2_rgba_eval_driver_roundtrip(tmp_path):
+    """train_transparent_i2v_stage2.py --eval flow (RGBA image -> premultiplied VAE latent + alpha offset -> UNet3D denoising
+    -> VAE decode -> UNet384 alpha decode -> gif / webp) on synthetic small checkpoints."""
+    from animate_anything_amd import eval_stage2
+    from animate_anything_amd.layerdiffuse import LatentTransparencyOffsetEncoder, UNet384
+    torch.manual_seed(0)
+    ckpt, alpha_ckpt = tmp_path / "unet_ckpt", tmp_path / "alpha_ckpt"
+    UNet3DConditionModel(**SMALL_UNET).save_pretrained(str(ckpt / "unet"))
+    AutoencoderKL(**SMALL_VAE).save_pretrained(str(ckpt / "vae"))
+    os.makedirs(ckpt / "scheduler")
+    json.dump({"_class_name": "DDIMScheduler", "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear",
+               "num_train_timesteps": 1000, "steps_offset": 1, "timestep_spacing": "leading"},
+              open(ckpt / "scheduler" / "scheduler_config.json", "w"))
+    os.makedirs(alpha_ckpt)
+    enc, dec = LatentTransparencyOffsetEncoder(), UNet384()
+    with torch.no_grad():
+        for p_ in list(enc.parameters()) + list(dec.parameters()):
+            if p_.abs().max() == 0:
+                p_.normal_(0.0, 0.05)
+    torch.save(enc.state_dict(), alpha_ckpt / "vae_alpha_encoder.pth")
+    torch.save(dec.state_dict(), alpha_ckpt / "vae_alpha_decoder.pth")
+    rng = np.random.default_rng(1)
+    rgba = rng.integers(0, 255, (128, 128, 4), dtype=np.uint8)
+    rgba[..., 3] = 0
+    rgba[32:96, 40:100, 3] = 255
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "obj.png")
+    torch.save({"prompt_embeds": torch.randn(1, 77, 128), "negative_prompt_embeds": torch.randn(1, 77, 128)}, tmp_path / "embeds.pt")
+    cfg = {"transparent_unet_pretrained_model_path": str(ckpt), "transparent_VAE_pretrained_model_path": str(alpha_ckpt),
+           "motion_mask": True, "motion_strength": True, "seed": 3, "output_dir": str(tmp_path / "out"), "iters": 1,
+           "validation_data": {"prompt": "", "prompt_image": str(tmp_path / "obj.png"), "prompt_embeds": str(tmp_path / "embeds.pt"),
+                               "num_frames": 3, "width": 128, "height": 128, "num_inference_steps": 2, "guidance_scale": 9, "fps": 6}}
+    yaml.safe_dump(cfg, open(tmp_path / "config2.yaml", "w"))
+    results = eval_stage2.main(["--config", str(tmp_path / "config2.yaml"), "--eval"])
+    assert len(results) == 1
+    _, frames, latents, pngs, alpha = results[0]
+    assert len(frames) == 3 and frames[0].shape == (128, 128, 3)
+    assert latents.shape == (1, 4, 3, 16, 16) and torch.isfinite(latents).all()
+    assert pngs.shape == (3, 128, 128, 4) and alpha.shape == (3, 128, 128) and set(np.unique(alpha).tolist()) <= {0, 255}
+    out = tmp_path / "out" / "obj"
+    assert (out / "0.gif").exists() and (out / "0_decoded_rgba.webp").exists() and (out / "0_decoded_alpha.webp").exists()
+    assert Image.open(out / "0_decoded_rgba.webp").n_frames >= 1
