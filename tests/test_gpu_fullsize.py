@@ -77,6 +77,34 @@ def test_unet_forward_at_the_metric_configuration():
     assert (got[0] - got[1]).abs().max().item() > 1e-3
 
 
+def test_full_architecture_at_the_real_eval_resolution_55x74():
+    """The reference's eval rescales to the image aspect ratio rounded to 8 (train.py:741-744): 440x592 px = 55x74 latents for
+    its sample images, which goes 55 -> 28 -> 14 -> 7 on the way down and needs the `upsample_size` path on the way up
+    (unet_3d_condition_mask.py:381-383,490-491).  Full v1.02 architecture, CFG batch 2, 2+1 frames, oracle computed live."""
+    from animate_anything_amd.unet3d import UNet3DConditionModel
+    ref, state = fullsize_oracle()
+    g = torch.Generator().manual_seed(77)
+    r = lambda *s: torch.randn(*s, generator=g)
+    h, w, frames = 55, 74, 2
+    mask = torch.zeros(1, 1, 1, h, w)
+    mask[..., 10:40, 20:60] = 1
+    sample, cond, text = r(1, 4, frames, h, w).repeat(2, 1, 1, 1, 1), r(1, 4, 1, h, w).repeat(2, 1, 1, 1, 1), r(2, 77, 1024)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        want = ref(sample, 651, text, cond, mask, motion=torch.tensor([5.0])).sample
+    del ref
+    net = UNet3DConditionModel(**FULL_UNET).eval()
+    net.load_state_dict(state)
+    del state
+    net = net.to(DT).cuda()
+    dev = lambda x: x.to(DT).cuda()
+    with torch.no_grad():
+        got = net(dev(sample), 651, dev(text), dev(cond), dev(mask), motion=torch.tensor([5.0])).sample.float().cpu()
+    assert got.shape == want.shape == (2, 4, frames, h, w)
+    assert ((got - want) ** 2).mean().item() < 1e-3
+    assert rel_err(got, want) < 3e-2
+
+
 # ------------------------------------------------------------------------------------------ contractions at real shapes
 @pytest.mark.parametrize("c1", [0, 640])
 def test_conv3x3_320_at_34x64x64(c1):
