@@ -26,7 +26,7 @@ class AaConvGemm(C.Structure):
         ("n_out", C.c_int32), ("n_pad", C.c_int32), ("k_pad", C.c_int32),
         ("rowvec_div", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
         ("act", C.c_int32), ("geglu", C.c_int32), ("bias_per_row", C.c_int32),
-        ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("k_order", C.c_int32), ("debug", C.c_int32), ("tile", C.c_int32), ("k_splits", C.c_int32), ("rowvec_ld", C.c_int32),
+        ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("k_order", C.c_int32), ("debug", C.c_int32), ("tile", C.c_int32), ("k_splits", C.c_int32), ("rowvec_ld", C.c_int32), ("acc_scale", C.c_float),
     ]
 
 
@@ -41,7 +41,7 @@ class AaGroupNorm(C.Structure):
 class AaAttnOperand(C.Structure):
     _fields_ = [
         ("ptr", C.c_void_p), ("outer_stride", C.c_int64), ("inner_stride", C.c_int64), ("pos_stride", C.c_int64),
-        ("ld", C.c_int32), ("col0", C.c_int32), ("outer_div", C.c_int32), ("_pad", C.c_int32),
+        ("ld", C.c_int32), ("col0", C.c_int32), ("outer_div", C.c_int32), ("seq_mod", C.c_int32),
     ]
 
 
@@ -81,9 +81,35 @@ class AaDpmStepTok(C.Structure):
     ]
 
 
+class AaBlend(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p), ("rowvec", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int64),
+        ("channels", C.c_int32), ("rowvec_div", C.c_int32), ("rowvec_mod", C.c_int32), ("rowvec_ld", C.c_int32),
+        ("a", C.c_float), ("b", C.c_float), ("act", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
+class AaPackFrames(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p * 3), ("src_channels", C.c_int32 * 3), ("src_batch", C.c_int32 * 3), ("src_f32", C.c_int32 * 3),
+        ("scale", C.c_void_p), ("scaled_src", C.c_int32), ("out", C.c_void_p),
+        ("batch", C.c_int32), ("frames", C.c_int32), ("hw", C.c_int32), ("out_channels", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
+class AaEulerStepTok(C.Structure):
+    _fields_ = [
+        ("v_tokens", C.c_void_p), ("latents", C.c_void_p), ("guidance", C.c_void_p), ("next_t", C.c_void_p),
+        ("next_t_count", C.c_int32), ("next_t_value", C.c_float), ("next_scale", C.c_void_p), ("next_scale_value", C.c_float),
+        ("clips", C.c_int32), ("channels", C.c_int32), ("frames", C.c_int32), ("hw", C.c_int32), ("ld", C.c_int32),
+        ("c_x", C.c_float), ("c_v", C.c_float), ("dtype", C.c_int32),
+    ]
+
+
 SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_groupnorm_workspace", "aa_groupnorm",
            "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step",
-           "aa_timestep_embedding", "aa_pack_latents", "aa_cfg_dpm_step_tokens")
+           "aa_timestep_embedding", "aa_pack_latents", "aa_cfg_dpm_step_tokens",
+           "aa_blend", "aa_pack_frames", "aa_cfg_euler_step_tokens")
 
 DEFAULT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaa_mi355.so")
 
@@ -119,6 +145,9 @@ def bind(path: str) -> C.CDLL:
     lib.aa_timestep_embedding.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.aa_pack_latents.argtypes = [C.POINTER(AaPackLatents), C.c_void_p]
     lib.aa_cfg_dpm_step_tokens.argtypes = [C.POINTER(AaDpmStepTok), C.c_void_p]
+    lib.aa_blend.argtypes = [C.POINTER(AaBlend), C.c_void_p]
+    lib.aa_pack_frames.argtypes = [C.POINTER(AaPackFrames), C.c_void_p]
+    lib.aa_cfg_euler_step_tokens.argtypes = [C.POINTER(AaEulerStepTok), C.c_void_p]
     for s in SYMBOLS[5:]:
         if s not in ("aa_groupnorm_workspace", "aa_conv_gemm_workspace"):
             getattr(lib, s).restype = C.c_int

@@ -425,7 +425,9 @@ int aa_attention(const AaAttention* d, void* stream) {
     for (const AaAttnOperand* x : ops) {
         if (!aligned16(x->ptr) || x->ld % 8 || x->col0 % 8) return fail(AA_E_ALIGN, "attention: operand rows must be 16-byte aligned");
         if (x->outer_div <= 0) return fail(AA_E_SHAPE, "attention: outer_div must be >= 1");
+        if (x->seq_mod < 0) return fail(AA_E_SHAPE, "attention: seq_mod must be >= 0");
     }
+    if (d->q.seq_mod || d->o.seq_mod) return fail(AA_E_SHAPE, "attention: seq_mod addressing is for K / V only");
     // K / V are read through buffer descriptors with 32-bit byte offsets; offsets >= 2^31 mean "zero"
     if (d->head_dim == 64 && (attn_extent_bytes(d->k, d->n_outer, d->n_inner, d->kv_len) >= ((int64_t)1 << 31) ||
         attn_extent_bytes(d->v, d->n_outer, d->n_inner, d->kv_len) >= ((int64_t)1 << 31)))
@@ -496,6 +498,59 @@ int aa_cfg_dpm_step_tokens(const AaDpmStepTok* d, void* stream) {
     else if (d->dtype == AA_BF16) AA_LAUNCH((cfg_dpm_step_tok_kernel<bf16_t>), grid, block, 0, stream, *d);
     else return fail(AA_E_DTYPE, "cfg_dpm_step_tokens: unsupported dtype %d", d->dtype);
     return finish("cfg_dpm_step_tokens");
+}
+
+int aa_blend(const AaBlend* d, void* stream) {
+    using namespace aa;
+    if (!d || !d->x || !d->out) return fail(AA_E_SHAPE, "blend: null operand");
+    if (d->rows <= 0 || d->channels <= 0 || d->channels % 8 || (d->rowvec && d->rowvec_div <= 0) || d->rowvec_mod < 0 ||
+        (d->rowvec_ld && d->rowvec_ld < d->channels) || d->rowvec_ld % 8)
+        return fail(AA_E_SHAPE, "blend: bad geometry (rows=%lld channels=%d)", (long long)d->rows, d->channels);
+    if (!aligned16(d->x) || !aligned16(d->out) || (d->y && !aligned16(d->y)) || (d->rowvec && !aligned16(d->rowvec)))
+        return fail(AA_E_ALIGN, "blend: operands must be 16-byte aligned");
+    int64_t blocks = (d->rows * (d->channels / 8) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (d->dtype == AA_F16) AA_LAUNCH((blend_kernel<f16_t>), grid, block, 0, stream, *d);
+    else if (d->dtype == AA_BF16) AA_LAUNCH((blend_kernel<bf16_t>), grid, block, 0, stream, *d);
+    else return fail(AA_E_DTYPE, "blend: unsupported dtype %d", d->dtype);
+    return finish("blend");
+}
+
+int aa_pack_frames(const AaPackFrames* d, void* stream) {
+    using namespace aa;
+    if (!d || !d->out) return fail(AA_E_SHAPE, "pack_frames: null operand");
+    int channels = 0;
+    for (int s = 0; s < 3; ++s)
+        if (d->src[s]) {
+            if (d->src_channels[s] <= 0 || d->src_batch[s] <= 0) return fail(AA_E_SHAPE, "pack_frames: source %d has no channels / batch", s);
+            channels += d->src_channels[s];
+        }
+    if (d->batch <= 0 || d->frames <= 0 || d->hw <= 0 || channels <= 0 || (d->out_channels != 8 && d->out_channels != 16) || channels > d->out_channels)
+        return fail(AA_E_SHAPE, "pack_frames: bad geometry (batch=%d frames=%d hw=%d channels=%d -> %d)", d->batch, d->frames, d->hw, channels, d->out_channels);
+    if (!aligned16(d->out)) return fail(AA_E_ALIGN, "pack_frames: out must be 16-byte aligned");
+    int64_t blocks = ((int64_t)d->batch * d->frames * d->hw + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const dim3 grid((unsigned)blocks), block(256);
+    const bool wide = d->out_channels == 16;
+    if (d->dtype == AA_F16) { if (wide) AA_LAUNCH((pack_frames_kernel<f16_t, 16>), grid, block, 0, stream, *d); else AA_LAUNCH((pack_frames_kernel<f16_t, 8>), grid, block, 0, stream, *d); }
+    else if (d->dtype == AA_BF16) { if (wide) AA_LAUNCH((pack_frames_kernel<bf16_t, 16>), grid, block, 0, stream, *d); else AA_LAUNCH((pack_frames_kernel<bf16_t, 8>), grid, block, 0, stream, *d); }
+    else return fail(AA_E_DTYPE, "pack_frames: unsupported dtype %d", d->dtype);
+    return finish("pack_frames");
+}
+
+int aa_cfg_euler_step_tokens(const AaEulerStepTok* d, void* stream) {
+    using namespace aa;
+    if (!d || !d->v_tokens || !d->latents) return fail(AA_E_SHAPE, "cfg_euler_step_tokens: null operand");
+    if (d->clips <= 0 || d->channels <= 0 || d->frames <= 0 || d->hw <= 0 || d->ld < d->channels || d->next_t_count < 0 || d->next_t_count > 256)
+        return fail(AA_E_SHAPE, "cfg_euler_step_tokens: bad geometry");
+    int64_t blocks = ((int64_t)d->clips * d->channels * d->frames * d->hw + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (d->dtype == AA_F16) AA_LAUNCH((cfg_euler_step_tok_kernel<f16_t>), grid, block, 0, stream, *d);
+    else if (d->dtype == AA_BF16) AA_LAUNCH((cfg_euler_step_tok_kernel<bf16_t>), grid, block, 0, stream, *d);
+    else return fail(AA_E_DTYPE, "cfg_euler_step_tokens: unsupported dtype %d", d->dtype);
+    return finish("cfg_euler_step_tokens");
 }
 
 }  // extern "C"

@@ -35,16 +35,19 @@ __host__ __device__ inline int attn_stages(int kv_len) { return kv_len > AT_KT ?
 __host__ __device__ inline int attn_lds_bytes(int kv_len) { return attn_stages(kv_len) * AT_TILE_BYTES; }
 
 // first token row of sequence (o, i), in rows of the operand's matrix
-__device__ __forceinline__ int64_t attn_seq_row(const AaAttnOperand& x, int o, int i) {
+// (seq_mod > 0: the operand is a table of seq_mod sequences and sequence number o * n_inner + i reads entry number % seq_mod)
+__device__ __forceinline__ int64_t attn_seq_row(const AaAttnOperand& x, int o, int i, int n_inner) {
+    if (x.seq_mod > 0) return (int64_t)((o * n_inner + i) % x.seq_mod) * x.outer_stride;
     return (int64_t)(o / x.outer_div) * x.outer_stride + (int64_t)i * x.inner_stride;
 }
 template <typename T>
-__device__ __forceinline__ const T* attn_row(const AaAttnOperand& x, int o, int i, int pos, int head) {
-    return reinterpret_cast<const T*>(x.ptr) + (attn_seq_row(x, o, i) + (int64_t)pos * x.pos_stride) * x.ld + x.col0 + head * 64;
+__device__ __forceinline__ const T* attn_row(const AaAttnOperand& x, int o, int i, int n_inner, int pos, int head) {
+    return reinterpret_cast<const T*>(x.ptr) + (attn_seq_row(x, o, i, n_inner) + (int64_t)pos * x.pos_stride) * x.ld + x.col0 + head * 64;
 }
 // bytes of the operand an attention call may touch (descriptor range)
 __host__ __device__ inline int64_t attn_extent_bytes(const AaAttnOperand& x, int n_outer, int n_inner, int len) {
-    const int64_t last = (int64_t)((n_outer - 1) / x.outer_div) * x.outer_stride + (int64_t)(n_inner - 1) * x.inner_stride +
+    const int64_t last = (x.seq_mod > 0 ? (int64_t)(x.seq_mod - 1) * x.outer_stride
+                                        : (int64_t)((n_outer - 1) / x.outer_div) * x.outer_stride + (int64_t)(n_inner - 1) * x.inner_stride) +
                          (int64_t)(len - 1) * x.pos_stride;
     return (last + 1) * x.ld * 2;
 }
@@ -76,7 +79,7 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) atte
     {
         const int q = q0 + ql;
         const bool ok = q < p.q_len;
-        const T* src = attn_row<T>(p.q, o, i, ok ? q : 0, head) + 8 * h;
+        const T* src = attn_row<T>(p.q, o, i, p.n_inner, ok ? q : 0, head) + 8 * h;
 #pragma unroll
         for (int dk = 0; dk < 4; ++dk) {
             Pack8<T> v;
@@ -92,8 +95,8 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) atte
     // instructions w*PER/2 .. of each.  Per lane: key and byte offset inside the row, fixed for the whole kernel.
     const BufRsrc r_k = make_rsrc(p.k.ptr, (unsigned)attn_extent_bytes(p.k, p.n_outer, p.n_inner, p.kv_len));
     const BufRsrc r_v = make_rsrc(p.v.ptr, (unsigned)attn_extent_bytes(p.v, p.n_outer, p.n_inner, p.kv_len));
-    const unsigned k_seq = (unsigned)((attn_seq_row(p.k, o, i) * p.k.ld + p.k.col0 + head * 64) * 2);
-    const unsigned v_seq = (unsigned)((attn_seq_row(p.v, o, i) * p.v.ld + p.v.col0 + head * 64) * 2);
+    const unsigned k_seq = (unsigned)((attn_seq_row(p.k, o, i, p.n_inner) * p.k.ld + p.k.col0 + head * 64) * 2);
+    const unsigned v_seq = (unsigned)((attn_seq_row(p.v, o, i, p.n_inner) * p.v.ld + p.v.col0 + head * 64) * 2);
     const unsigned k_key = (unsigned)(p.k.pos_stride * p.k.ld * 2), v_key = (unsigned)(p.v.pos_stride * p.v.ld * 2);   // bytes per key
     // K piece of this lane: key (lane>>3) of the instruction, d-slot (lane&7) ^ swizzle(key row inside the tile)
     const int kk = lane >> 3;
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) atte
         const float inv = 1.0f / l_tot;
         const int q = q0 + ql;
         if (q < p.q_len) {
-            T* dst = const_cast<T*>(attn_row<T>(p.o, o, i, q, head));
+            T* dst = const_cast<T*>(attn_row<T>(p.o, o, i, p.n_inner, q, head));
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AaAttention p) 
         Pack8<T> raw;
         raw.raw = u32x4{0u, 0u, 0u, 0u};
         if (active) raw.raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.q.ptr) +
-                                  (attn_seq_row(p.q, o, i) + (int64_t)q * p.q.pos_stride) * p.q.ld + p.q.col0 + head * 8);
+                                  (attn_seq_row(p.q, o, i, p.n_inner) + (int64_t)q * p.q.pos_stride) * p.q.ld + p.q.col0 + head * 8);
 #pragma unroll
         for (int d = 0; d < 8; ++d) { qv[d] = (float)raw.e[d] * sl2e; acc[d] = 0.0f; }
     }
@@ -291,9 +294,9 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AaAttention p) 
             u32x4 kr = {0u, 0u, 0u, 0u}, vr = {0u, 0u, 0u, 0u};
             if (key < p.kv_len) {
                 kr = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.k.ptr) +
-                         (attn_seq_row(p.k, o, i) + (int64_t)key * p.k.pos_stride) * p.k.ld + p.k.col0 + head * 8);
+                         (attn_seq_row(p.k, o, i, p.n_inner) + (int64_t)key * p.k.pos_stride) * p.k.ld + p.k.col0 + head * 8);
                 vr = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.v.ptr) +
-                         (attn_seq_row(p.v, o, i) + (int64_t)key * p.v.pos_stride) * p.v.ld + p.v.col0 + head * 8);
+                         (attn_seq_row(p.v, o, i, p.n_inner) + (int64_t)key * p.v.pos_stride) * p.v.ld + p.v.col0 + head * 8);
             }
             *reinterpret_cast<u32x4*>(sK + tid * 8) = kr;
             *reinterpret_cast<u32x4*>(sV + tid * 8) = vr;
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AaAttention p) 
 #pragma unroll
         for (int c = 0; c < 8; ++c) out.e[c] = (T)(acc[c] * inv);
         *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(const_cast<void*>(p.o.ptr)) +
-            (attn_seq_row(p.o, o, i) + (int64_t)q * p.o.pos_stride) * p.o.ld + p.o.col0 + head * 8) = out.raw;
+            (attn_seq_row(p.o, o, i, p.n_inner) + (int64_t)q * p.o.pos_stride) * p.o.ld + p.o.col0 + head * 8) = out.raw;
     }
 }
 

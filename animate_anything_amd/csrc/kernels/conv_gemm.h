@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(CG_THREADS) conv_gemm_kernel(const AaConvGemm 
                     if (p.bias_per_row && bias) v += (float)bias[m];
                     if (rowvec) v += (float)rowvec[(int64_t)(m / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out) + n];
                     if (p.act == AA_ACT_SILU) v = silu_f(v);
+                    if (p.acc_scale != 0.0f) v *= p.acc_scale;
                     if (resid) v += (float)resid[(int64_t)m * p.ldr + n];
                     store_out<T>(p.out, p.out_dtype, (int64_t)m * p.ldo + n, v * p.out_scale);
                 }

@@ -46,7 +46,8 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
     const T* bias = reinterpret_cast<const T*>(p.bias);
     T* out = reinterpret_cast<T*>(p.out);
     const int n_cols = p.geglu ? (p.n_out >> 1) : p.n_out;
-    const bool post = resid || p.out_scale != 1.0f;
+    const float acc_scale = p.acc_scale != 0.0f ? p.acc_scale : 1.0f;
+    const bool post = resid || p.out_scale != 1.0f || acc_scale != 1.0f;
     const bool silu = p.act == AA_ACT_SILU;
     const bool pre_is_rv = rowvec != nullptr;             // the prefetch registers carry the row vector, else the residual
 #define AA_ZERO4 (u32x4{0u, 0u, 0u, 0u})          /* a prvalue: `c ? arr[i] : zero_variable` would select between ADDRESSES and pin arr in scratch */
@@ -79,7 +80,7 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
                     Pack8<T> r; r.raw = AA_ZERO4;
                     if (rs) { if (pre_is_rv) { if (nc + 8 * q + 8 <= n_cols) r.raw = *reinterpret_cast<const u32x4*>(rs + nc + 8 * q); } else r.raw = pv; }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[q][e] = (v[q][e] + (float)r.e[e]) * p.out_scale;
+                    for (int e = 0; e < 8; ++e) v[q][e] = (v[q][e] * acc_scale + (float)r.e[e]) * p.out_scale;
                 }
                 Pack8<T> o;
 #pragma unroll
@@ -563,6 +564,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const AaConvGemm p, 
         if (p.act == AA_ACT_SILU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        }
+        if (p.acc_scale != 0.0f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.acc_scale;
         }
         if (resid) {                                                 // (fp32 until the single final rounding, like the fused epilogue)
 #pragma unroll

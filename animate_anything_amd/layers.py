@@ -117,15 +117,15 @@ class LayerNorm(nn.LayerNorm):
 
 # ------------------------------------------------------------------------------------- embeddings
 class TimestepEmbedding(nn.Module):
-    """diffusers TimestepEmbedding(act='silu', cond_proj_dim).  `tokens` returns
+    """diffusers TimestepEmbedding(act='silu', cond_proj_dim, out_dim).  `tokens` returns
     silu(linear_2(...)) when `final_silu` since the only consumers are the resnets'
     time_emb_proj(silu(temb))."""
 
-    def __init__(self, in_channels, time_embed_dim, cond_proj_dim=None):
+    def __init__(self, in_channels, time_embed_dim, cond_proj_dim=None, out_dim=None):
         super().__init__()
         self.linear_1 = Linear(in_channels, time_embed_dim)
         self.cond_proj = Linear(cond_proj_dim, in_channels, bias=False) if cond_proj_dim else None
-        self.linear_2 = Linear(time_embed_dim, time_embed_dim)
+        self.linear_2 = Linear(time_embed_dim, out_dim or time_embed_dim)
 
     def tokens(self, sample, condition=None, final_silu=False):
         if condition is not None:
@@ -263,7 +263,13 @@ class Attention(nn.Module):
             return kv
         return ops.conv_gemm(text_tokens, self.fused(), ops.linear_geom(text_tokens.shape[0]))
 
-    def self_tokens(self, normed, residual, g: Grid, temporal: bool):
+    def cross_rowvec(self, text_tokens):
+        """A ONE-token context (the CLIP image embedding of the SVD path): softmax over a single key is exactly 1, the
+        cross-attention output of every query of clip b is to_out(to_v(ctx_b)) - a row vector per clip, [clips, query_dim]."""
+        kv = self.text_kv(text_tokens)
+        return self.to_out[0].tokens(kv[:, self.inner:].contiguous())
+
+    def self_tokens(self, normed, residual, g: Grid, temporal: bool, **epilogue):
         qkv = ops.conv_gemm(normed, self.fused(), ops.linear_geom(normed.shape[0]))
         c = self.inner
         if temporal:
@@ -272,12 +278,20 @@ class Attention(nn.Module):
         else:
             st = (g.hw, 0, 1)
             a = ops.attention(qkv, 0, qkv, c, qkv, 2 * c, self.heads, g.images, 1, g.hw, g.hw, st, st)
-        return self.to_out[0].tokens(a, residual=residual)
+        return self.to_out[0].tokens(a, residual=residual, **epilogue)
 
     def cross_tokens(self, normed, residual, g: Grid, kv, kv_len):
         q = self.to_q.tokens(normed)
         a = ops.attention(q, 0, kv, 0, kv, self.inner, self.heads, g.images, 1, g.hw, kv_len,
                           (g.hw, 0, 1), (kv_len, 0, 1), kv_outer_div=g.frames)
+        return self.to_out[0].tokens(a, residual=residual)
+
+    def cross_tokens_temporal(self, normed, residual, g: Grid, kv, kv_len, kv_seq_mod=0):
+        """Queries = the frames of one pixel, keys = a clip's context tokens (diffusers TemporalBasicTransformerBlock.attn2);
+        kv_seq_mod > 0: pixel sequence number n = clip*h*w + pixel reads the context of clip n % kv_seq_mod."""
+        q = self.to_q.tokens(normed)
+        a = ops.attention(q, 0, kv, 0, kv, self.inner, self.heads, g.clips, g.hw, g.frames, kv_len,
+                          (g.frames * g.hw, 1, g.hw), (kv_len, 0, 1), kv_seq_mod=kv_seq_mod)
         return self.to_out[0].tokens(a, residual=residual)
 
 
@@ -303,9 +317,9 @@ class GEGLU(nn.Module):
 
 
 class FeedForward(nn.Module):
-    def __init__(self, dim, mult=4):
+    def __init__(self, dim, mult=4, dim_out=None):
         super().__init__()
-        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim)])
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim_out or dim)])
 
     def tokens(self, x, residual):
         return self.net[2].tokens(self.net[0].tokens(x), residual=residual)

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (AA_ACT_NONE, AA_ACT_SILU, AA_BF16, AA_F16, AA_F32, AaAttention, AaAttnOperand,
-                   AaConvGemm, AaDpmStep, AaDpmStepTok, AaGroupNorm, AaPackLatents)
+                   AaBlend, AaConvGemm, AaDpmStep, AaDpmStepTok, AaEulerStepTok, AaGroupNorm, AaPackFrames, AaPackLatents)
 
 _DT = {torch.float16: AA_F16, torch.bfloat16: AA_BF16, torch.float32: AA_F32}
 
@@ -323,7 +323,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
               rowvec: Optional[torch.Tensor] = None, rowvec_div: int = 1,
               residual: Optional[torch.Tensor] = None, act: int = AA_ACT_NONE, out_dtype=None,
               out_scale: float = 1.0, bias_per_row: bool = False, out: Optional[torch.Tensor] = None,
-              bias: Optional[torch.Tensor] = "packed") -> torch.Tensor:
+              bias: Optional[torch.Tensor] = "packed", acc_scale: float = 1.0) -> torch.Tensor:
     lib = _lib.get()
     b = pw.bias if isinstance(bias, str) else bias
     _check(x0, x1, pw.w, b, residual, out)
@@ -353,7 +353,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
                 rv = rowvec[(i0 * ro) // rowvec_div:]
             conv_gemm(x0[i0 * ri:(i0 + n) * ri], pw, gi, None if x1 is None else x1[i0 * ri:(i0 + n) * ri], rv, rowvec_div,
                       None if residual is None else residual[i0 * ro:(i0 + n) * ro], act, out_dtype, out_scale, False,
-                      out[i0 * ro:(i0 + n) * ro], bias)
+                      out[i0 * ro:(i0 + n) * ro], bias, acc_scale)
         return out
     if c0 + c1 != pw.cin:
         raise RuntimeError(f"conv_gemm: activation has {c0}+{c1} channels, weight expects {pw.cin}")
@@ -376,6 +376,9 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.ldr = 0 if residual is None else residual.stride(0)
     d.act, d.geglu, d.bias_per_row = act, int(pw.geglu), int(bias_per_row)
     d.dtype, d.out_dtype, d.out_scale = _DT[x0.dtype], _DT[odt], out_scale
+    d.acc_scale = 0.0 if acc_scale == 1.0 else float(acc_scale)
+    if acc_scale == 0.0:
+        raise ValueError("conv_gemm: acc_scale == 0 is not representable (0 means 1 in the C ABI)")
     d.k_order = pw.k_order
     d.debug = DEBUG_ABLATE
     d.tile, d.k_splits = -1, K_SPLITS
@@ -444,7 +447,8 @@ def _operand(t: torch.Tensor, col0: int, outer_stride: int, inner_stride: int, p
 
 def attention(q: torch.Tensor, q_col0: int, k: torch.Tensor, k_col0: int, v: torch.Tensor, v_col0: int,
               heads: int, n_outer: int, n_inner: int, q_len: int, kv_len: int,
-              q_strides, kv_strides, kv_outer_div: int = 1, scale: Optional[float] = None, head_dim: int = 64) -> torch.Tensor:
+              q_strides, kv_strides, kv_outer_div: int = 1, scale: Optional[float] = None, head_dim: int = 64,
+              kv_seq_mod: int = 0) -> torch.Tensor:
     """softmax(q k^T * scale) v for every (outer, inner, head).  `*_strides` = (outer, inner, pos)
     row strides of the token matrices; output rows use the q addressing, columns [0, heads*64)."""
     lib = _lib.get()
@@ -457,6 +461,7 @@ def attention(q: torch.Tensor, q_col0: int, k: torch.Tensor, k_col0: int, v: tor
     d.k = _operand(k, k_col0, *kv_strides, outer_div=kv_outer_div)
     d.v = _operand(v, v_col0, *kv_strides, outer_div=kv_outer_div)
     d.o = _operand(out, 0, *q_strides)
+    d.k.seq_mod = d.v.seq_mod = kv_seq_mod       # > 0: sequence number n reads K / V table entry n % kv_seq_mod
     d.n_outer, d.n_inner, d.heads, d.head_dim = n_outer, n_inner, heads, head_dim
     d.q_len, d.kv_len, d.dtype = q_len, kv_len, _DT[q.dtype]
     d.scale = float(head_dim) ** -0.5 if scale is None else scale
@@ -532,3 +537,68 @@ def cfg_dpm_step_tokens(eps_tokens, latents, x0_prev, latents_lp, guidance, coef
     d.dtype = _DT[eps_tokens.dtype]
     assert latents.dtype == torch.float32 and x0_prev.dtype == torch.float32
     _run(lib.aa_cfg_dpm_step_tokens, C.byref(d), _stream(latents))
+
+
+# ------------------------------------------------------------------------------------- Stable-Video-Diffusion glue
+def blend(x: torch.Tensor, y: Optional[torch.Tensor] = None, a: float = 1.0, b: float = 1.0,
+          rowvec: Optional[torch.Tensor] = None, rowvec_div: int = 1, rowvec_mod: int = 0, act: int = AA_ACT_NONE,
+          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(a*x + b*y + rowvec[(row // rowvec_div) % rowvec_mod]) on [rows, C] token matrices (diffusers AlphaBlender etc.)."""
+    lib = _lib.get()
+    _check(x, y, out)
+    if rowvec is not None and ((not rowvec.is_cuda and not _lib.host_pointers_ok()) or rowvec.stride(-1) != 1):
+        raise RuntimeError("blend: rowvec must be a GPU tensor with contiguous rows")
+    o = torch.empty_like(x) if out is None else out
+    d = AaBlend()
+    d.x, d.y, d.rowvec, d.out = _ptr(x), _ptr(y), _ptr(rowvec), _ptr(o)
+    d.rows, d.channels = x.shape[0], x.shape[1]
+    d.rowvec_div, d.rowvec_mod = rowvec_div, rowvec_mod
+    d.rowvec_ld = 0 if rowvec is None or rowvec.dim() < 2 else rowvec.stride(0)
+    d.a, d.b, d.act, d.dtype = float(a), float(b), act, _DT[x.dtype]
+    _run(lib.aa_blend, C.byref(d), _stream(x))
+    return o
+
+
+def pack_frames(sources, batch: int, dtype, scale: Optional[torch.Tensor] = None, scaled_src: int = -1,
+                out_channels: int = 16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """cat(sources, dim=2) of [Bs, F, Cs, h, w] tensors (fp32 or `dtype`) -> tokens [batch*F*h*w, out_channels];
+    source `scaled_src` is multiplied by the DEVICE scalar `scale` (EulerDiscreteScheduler.scale_model_input)."""
+    lib = _lib.get()
+    srcs = [s_ for s_ in sources if s_ is not None]
+    _check(*srcs, scale, out)
+    assert 1 <= len(srcs) <= 3
+    _, frames, _, h, w = srcs[0].shape
+    y = torch.empty(batch * frames * h * w, out_channels, dtype=dtype, device=srcs[0].device) if out is None else out
+    d = AaPackFrames()
+    k = 0
+    for i, s_ in enumerate(sources):
+        if s_ is None:
+            continue
+        assert s_.shape[1] == frames and s_.shape[3:] == (h, w) and s_.dtype in (torch.float32, dtype)
+        d.src[k], d.src_channels[k], d.src_batch[k], d.src_f32[k] = _ptr(s_), s_.shape[2], s_.shape[0], int(s_.dtype == torch.float32)
+        if i == scaled_src:
+            d.scaled_src = k
+        k += 1
+    if scaled_src < 0 or scale is None:
+        d.scaled_src = -1
+    d.scale, d.out = _ptr(scale), _ptr(y)
+    d.batch, d.frames, d.hw, d.out_channels, d.dtype = batch, frames, h * w, out_channels, _DT[dtype]
+    _run(lib.aa_pack_frames, C.byref(d), _stream(srcs[0]))
+    return y
+
+
+def cfg_euler_step_tokens(v_tokens, latents, guidance, c_x, c_v, next_t=None, next_t_value=0.0, next_scale=None,
+                          next_scale_value=1.0):
+    """Per-frame guidance + Euler (v-prediction) update x' = c_x x + c_v v, reading the UNet's token-layout output;
+    latents fp32 [clips, F, C, h, w] updated in place; `guidance` DEVICE fp32 [F] or None."""
+    lib = _lib.get()
+    _check(v_tokens, latents, guidance, next_t, next_scale)
+    clips, frames, c, h, w = latents.shape
+    assert latents.dtype == torch.float32 and (guidance is None or (guidance.dtype == torch.float32 and guidance.numel() == frames))
+    d = AaEulerStepTok()
+    d.v_tokens, d.latents, d.guidance = _ptr(v_tokens), _ptr(latents), _ptr(guidance)
+    d.next_t, d.next_t_count, d.next_t_value = _ptr(next_t), 0 if next_t is None else next_t.numel(), float(next_t_value)
+    d.next_scale, d.next_scale_value = _ptr(next_scale), float(next_scale_value)
+    d.clips, d.channels, d.frames, d.hw, d.ld = clips, c, frames, h * w, v_tokens.stride(0)
+    d.c_x, d.c_v, d.dtype = float(c_x), float(c_v), _DT[v_tokens.dtype]
+    _run(lib.aa_cfg_euler_step_tokens, C.byref(d), _stream(latents))

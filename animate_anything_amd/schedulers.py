@@ -145,3 +145,86 @@ class DPMSolverMultistepScheduler:
         self._step_index += 1
         prev = prev.to(sample.dtype)
         return SchedulerOutput(prev_sample=prev) if return_dict else (prev,)
+
+
+class EulerDiscreteScheduler:
+    """diffusers==0.24.0 EulerDiscreteScheduler in the configuration Stable Video Diffusion ships (the scheduler the
+    reference's SVD pipelines drive: /root/reference/models/pipeline.py:399-401 set_timesteps, :419 scale_model_input,
+    :440 step; /root/reference/train_svd.py:732-733): v-prediction, Karras sigmas between sigma_min and sigma_max,
+    continuous timesteps t = 0.25 ln(sigma), leading spacing (init_noise_sigma = sqrt(sigma_max^2 + 1)).
+
+    The schedule is host math (float64, sigmas rounded to float32 like diffusers); the tensor update is either the torch
+    expression of `step()` or the fused HIP kernel `aa_cfg_euler_step_tokens` fed by `coefficients()`."""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 prediction_type="v_prediction", interpolation_type="linear", use_karras_sigmas=True, sigma_min=0.002,
+                 sigma_max=700.0, timestep_spacing="leading", timestep_type="continuous", steps_offset=1, **_):
+        if prediction_type != "v_prediction" or not use_karras_sigmas or timestep_type != "continuous":
+            raise NotImplementedError("only v_prediction / Karras sigmas / continuous timesteps (the SVD configuration)")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                      beta_schedule=beta_schedule, prediction_type=prediction_type,
+                                      interpolation_type=interpolation_type, use_karras_sigmas=use_karras_sigmas,
+                                      sigma_min=sigma_min, sigma_max=sigma_max, timestep_spacing=timestep_spacing,
+                                      timestep_type=timestep_type, steps_offset=steps_offset)
+        acp = np.cumprod(1.0 - _betas(num_train_timesteps, beta_start, beta_end, beta_schedule))
+        self._train_sigmas = ((1 - acp) / acp) ** 0.5
+        self.timesteps = None
+        self.sigmas = None
+        self._step_index = None
+
+    @classmethod
+    def from_config(cls, config, **overrides):
+        cfg = dict(vars(config)) if isinstance(config, SimpleNamespace) else dict(config)
+        cfg.update(overrides)
+        return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        c = self.config
+        s_min = c.sigma_min if c.sigma_min is not None else float(self._train_sigmas[0])
+        s_max = c.sigma_max if c.sigma_max is not None else float(self._train_sigmas[-1])
+        rho = 7.0
+        ramp = np.linspace(0, 1, num_inference_steps)
+        lo, hi = s_min ** (1 / rho), s_max ** (1 / rho)
+        sig = ((hi + ramp * (lo - hi)) ** rho).astype(np.float32)
+        self._sig = np.concatenate([sig.astype(np.float64), [0.0]])
+        self.sigmas = torch.from_numpy(np.concatenate([sig, np.zeros(1, np.float32)]))
+        ts = torch.from_numpy((0.25 * np.log(sig.astype(np.float64))).astype(np.float32))
+        self.timesteps = ts.to(device) if device is not None else ts
+        self._ts = [float(t) for t in ts]
+        self.num_inference_steps = num_inference_steps
+        self._step_index = None
+
+    @property
+    def init_noise_sigma(self):
+        m = float(self._sig.max())
+        return m if self.config.timestep_spacing in ("linspace", "trailing") else (m * m + 1.0) ** 0.5
+
+    def index_for_timestep(self, timestep):
+        t = float(timestep)
+        return min(range(len(self._ts)), key=lambda i: abs(self._ts[i] - t))
+
+    def input_scale(self, step_index: int) -> float:
+        s = self._sig[step_index]
+        return 1.0 / math.sqrt(s * s + 1.0)
+
+    def scale_model_input(self, sample, timestep):
+        i = self._step_index if self._step_index is not None else self.index_for_timestep(timestep)
+        return sample * self.input_scale(i)
+
+    def coefficients(self, step_index: int):
+        """x' = c_x * x + c_v * v for  x0 = v * (-s / sqrt(s^2+1)) + x / (s^2+1),  x' = x + (x - x0) / s * (s_next - s)."""
+        s, sn = self._sig[step_index], self._sig[step_index + 1]
+        r = (sn - s) / s
+        return dict(c_x=1.0 + r * (1.0 - 1.0 / (s * s + 1.0)), c_v=r * s / math.sqrt(s * s + 1.0))
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+        """diffusers-compatible tensor update (torch ops, fp32 arithmetic)."""
+        if self._step_index is None:
+            self._step_index = self.index_for_timestep(timestep)
+        s, sn = self._sig[self._step_index], self._sig[self._step_index + 1]
+        x = sample.float()
+        x0 = model_output.float() * (-s / math.sqrt(s * s + 1.0)) + x / (s * s + 1.0)
+        prev = (x + (x - x0) / s * (sn - s)).to(sample.dtype)
+        self._step_index += 1
+        return SchedulerOutput(prev_sample=prev, pred_original_sample=x0.to(sample.dtype)) if return_dict else (prev,)

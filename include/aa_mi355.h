@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AA_VERSION 101
+#define AA_VERSION 102
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
@@ -56,7 +56,7 @@ const char* aa_last_error(void);
  *   nn.Conv3d (3,1,1)           kh=3, kw=1 with h=T, w=H*W  (TemporalConvLayer, unet_3d_blocks.py:276..808)
  * Epilogue, in order: + bias[n] (or bias[m]); + rowvec[m / rowvec_div, n] (time embedding,
  * diffusers ResnetBlock2D); activation; GEGLU pairing (diffusers GEGLU: value * gelu_erf(gate));
- * + residual[m, n]; * out_scale; store as `out_dtype`.
+ * * acc_scale; + residual[m, n]; * out_scale; store as `out_dtype`.
  * W is pre-packed by the host: [n_pad, k_pad] row-major, k ordered (tap, channel) - or, see k_order,
  * (64-channel chunk, tap, channel) for multi-tap filters - zero padded,
  * and for GEGLU interleaved in blocks of 32 value rows / 32 gate rows (geglu = 32: the value block and its gate
@@ -93,6 +93,8 @@ typedef struct AaConvGemm {
     int32_t k_splits;      /* 0: library decides whether to split K; >= 1: this many K ranges (needs the workspace
                               aa_conv_gemm_workspace reports for the same descriptor; ignored when not applicable) */
     int32_t rowvec_ld;     /* row pitch of `rowvec` in elements (a slice of a wider matrix); 0 = n_out */
+    float acc_scale;       /* factor on the activated value in front of the residual add; 0 means 1 (version 102: the learned
+                              spatial/temporal blend of diffusers AlphaBlender, x_spatial + (1 - alpha) * temporal branch) */
 } AaConvGemm;
 
 /* Bytes of fp32 scratch with which aa_conv_gemm would split the K loop of this call over several workgroups
@@ -160,7 +162,10 @@ int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y,
 typedef struct AaAttnOperand {
     const void* ptr;
     int64_t outer_stride, inner_stride, pos_stride;   /* in rows (tokens) */
-    int32_t ld, col0, outer_div, _pad;
+    int32_t ld, col0, outer_div;
+    int32_t seq_mod;   /* 0: the addressing above.  > 0 (version 102): the operand is a table of seq_mod sequences, outer_stride rows
+                          apart, and sequence number o * n_inner + i reads entry (number % seq_mod) - the context addressing of
+                          diffusers==0.24.0 TransformerSpatioTemporalModel (time_context broadcast as [h*w, batch]) */
 } AaAttnOperand;
 
 typedef struct AaAttention {
@@ -254,6 +259,77 @@ typedef struct AaDpmStepTok {
 } AaDpmStepTok;
 
 int aa_cfg_dpm_step_tokens(const AaDpmStepTok* d, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Stable-Video-Diffusion path (version 102; reference models/pipeline.py:223-731, train_svd.py:726-826 driving diffusers'
+ * UNetSpatioTemporalConditionModel / AutoencoderKLTemporalDecoder / EulerDiscreteScheduler).
+ *
+ * aa_blend: out[r, :] = act( a * x[r, :] + b * y[r, :] + rowvec[(r / rowvec_div) % rowvec_mod, :] ) on [rows][channels]
+ * token matrices (channels % 8 == 0, contiguous rows); y and rowvec may be NULL, rowvec_mod 0 = no wrap.  Covers
+ *   diffusers AlphaBlender                   alpha * x_spatial + (1 - alpha) * x_temporal (TransformerSpatioTemporalModel),
+ *   `hidden_states_mix + emb`                the per-frame position embedding in front of the temporal transformer block
+ *                                            (rowvec = [frames][C], rowvec_div = h*w, rowvec_mod = frames),
+ *   silu(emb + aug_emb)                      the summed time / added-time-ids embedding in front of the resnets' projections.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct AaBlend {
+    const void* x;
+    const void* y;         /* may be NULL */
+    const void* rowvec;    /* may be NULL */
+    void* out;             /* may alias x */
+    int64_t rows;
+    int32_t channels;
+    int32_t rowvec_div, rowvec_mod, rowvec_ld;   /* rowvec_ld: row pitch in elements (0 = channels) */
+    float a, b;
+    int32_t act;           /* AA_ACT_* */
+    int32_t dtype;
+} AaBlend;
+
+int aa_blend(const AaBlend* d, void* stream);
+
+/* aa_pack_frames: the SVD UNet's input assembly (reference models/pipeline.py:417-422, :683-691):
+ *   latent_model_input = scheduler.scale_model_input(cat([latents] * 2), t)          (* 1 / sqrt(sigma^2 + 1))
+ *   cat([mask, latent_model_input, image_latents], dim=2)                            [B, F, 9, h, w]
+ * written as the channels-last token matrix [batch*frames*hw][out_channels] (zero padded) that conv_in reads.  Up to three
+ * sources [src_batch][frames][src_channels][hw] are concatenated along the channel axis; batch element b reads
+ * b % src_batch of each (the guidance halves share latents and mask).  Source `scaled_src` (or none: -1) is multiplied
+ * by *scale, a DEVICE float (so a captured graph can be replayed with the next sigma). */
+typedef struct AaPackFrames {
+    const void* src[3];        /* unused entries NULL */
+    int32_t src_channels[3];
+    int32_t src_batch[3];
+    int32_t src_f32[3];        /* 1: fp32 source, 0: storage dtype */
+    const float* scale;        /* may be NULL (= 1) */
+    int32_t scaled_src;
+    void* out;
+    int32_t batch, frames, hw;
+    int32_t out_channels;      /* 8 or 16, >= sum of src_channels */
+    int32_t dtype;
+} AaPackFrames;
+
+int aa_pack_frames(const AaPackFrames* d, void* stream);
+
+/* aa_cfg_euler_step_tokens: per-frame classifier-free guidance + EulerDiscreteScheduler.step (v-prediction) reading the
+ * UNet's token-layout output [(2*)clips*frames*hw][ld] (reference models/pipeline.py:435-440, :704-708):
+ *   v = v_uncond + guidance[frame] * (v_cond - v_uncond)            (guidance NULL: clips rows only, no guidance)
+ *   x0 = v * (-sigma / sqrt(sigma^2+1)) + x / (sigma^2+1);  x' = x + (x - x0) / sigma * (sigma_next - sigma)
+ * folded by the caller into x' = c_x * x + c_v * v.  Updates the fp32 latents [clips][frames][channels][hw] in place and
+ * writes the next step's timestep(s) / input scale for aa_timestep_embedding / aa_pack_frames. */
+typedef struct AaEulerStepTok {
+    const void* v_tokens;
+    void* latents;            /* fp32, updated in place */
+    const float* guidance;    /* DEVICE [frames] or NULL */
+    float* next_t;            /* device array receiving next_t_value (next_t_count <= 256 entries), may be NULL */
+    int32_t next_t_count;
+    float next_t_value;
+    float* next_scale;        /* device float receiving next_scale_value, may be NULL */
+    float next_scale_value;
+    int32_t clips, channels, frames, hw;
+    int32_t ld;               /* row pitch of the token matrix in elements (>= channels) */
+    float c_x, c_v;
+    int32_t dtype;
+} AaEulerStepTok;
+
+int aa_cfg_euler_step_tokens(const AaEulerStepTok* d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -62,3 +62,48 @@ def fullsize_oracle():
     state = seeded_state(ref)
     ref.load_state_dict(state)
     return ref, state
+
+
+# ---------------------------------------------------------------------------- Stable-Video-Diffusion path (BASELINE.json configs[3])
+SMALL_SVD_UNET = dict(in_channels=9, block_out_channels=(64, 128, 256, 256), num_attention_heads=(1, 2, 4, 4),
+                      cross_attention_dim=128, addition_time_embed_dim=64, projection_class_embeddings_input_dim=192,
+                      num_frames=4)
+SMALL_SVD_VAE = dict(block_out_channels=(32, 64, 128, 128))
+FULL_SVD_UNET = dict(in_channels=9, num_frames=14)       # stable-video-diffusion-img2vid + the reference's mask channel
+
+
+def svd_state(ref, seed=0):
+    """Seeded weights; the AlphaBlender mix factors are drawn at random so every blend is a real mixture."""
+    state = seeded_state(ref, seed)
+    g = torch.Generator().manual_seed(seed + 5)
+    for k in state:
+        if k.endswith("mix_factor"):
+            state[k] = torch.randn(1, generator=g)
+    return state
+
+
+def svd_unet_inputs(b=2, frames=14, h=72, w=128, channels=9, text_len=1, text_dim=1024, seed=4321):
+    """One CFG-doubled SVD UNet call as MaskStableVideoDiffusionPipeline assembles it (models/pipeline.py:417-431):
+    [mask | scaled noisy latents | image latents] per frame, the unconditional half with zero image latents / embedding."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    lat = r(1, frames, 4, h, w)
+    cond = r(1, 1, 4, h, w).repeat(1, frames, 1, 1, 1)
+    emb = r(1, text_len, text_dim)
+    mask = torch.zeros(1, frames, 1, h, w)
+    mask[..., h // 4: h - h // 4, w // 4: w - w // 4] = 1
+    parts = [mask.repeat(b, 1, 1, 1, 1)] if channels == 9 else []
+    x = torch.cat(parts + [lat.repeat(b, 1, 1, 1, 1), torch.cat([torch.zeros_like(cond), cond])[:b]], dim=2)
+    ctx = torch.cat([torch.zeros_like(emb), emb])[:b]
+    ids = torch.tensor([[6.0, 127.0, 0.02]]).repeat(b, 1)
+    return dict(sample=x, t=1.3, text=ctx, ids=ids)
+
+
+def fullsize_svd_oracle():
+    """The full SVD architecture with seeded weights (fp32, CPU); returns (module, state dict)."""
+    import oracle.svd as O
+    torch.manual_seed(0)
+    ref = O.UNetSpatioTemporalConditionModel(**FULL_SVD_UNET).eval()
+    state = svd_state(ref)
+    ref.load_state_dict(state)
+    return ref, state
