@@ -69,3 +69,10 @@ w = ops.pack_weight(rnd(1280, 1280), rnd(1280))
 probe("linear K=1280 N=1280 M=8704", lambda: ops.conv_gemm(x1, w, ops.linear_geom(M3)), [3, 15, 23, 24])
 w = ops.pack_weight(rnd(1280, 1280, 3, 3), rnd(1280))
 probe("conv3x3 1280 M=8704", lambda: ops.conv_gemm(x1, w, ops.conv3x3_geom(34, 16, 16)), [3, 15, 23, 24])
+# short-K contractions of the first level (the epilogue-heavy ones)
+wg = ops.pack_weight(rnd(2560, 320), rnd(2560), geglu=True)
+probe("geglu K=320 N=2560", lambda: ops.conv_gemm(x320, wg, ops.linear_geom(M)), [3, 15, 27, 12, 33, 25])
+w = ops.pack_weight(rnd(320, 320), rnd(320))
+probe("linear K=320 N=320 +res", lambda: ops.conv_gemm(x320, w, ops.linear_geom(M), residual=res), [4, 14, 26, 11, 30])
+w = ops.pack_weight(rnd(960, 320))
+probe("linear qkv K=320 N=960", lambda: ops.conv_gemm(x320, w, ops.linear_geom(M)), [4, 14, 26, 11, 30])
