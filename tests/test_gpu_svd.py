@@ -98,25 +98,32 @@ def test_small_temporal_vae_matches_oracle():
     assert rel_err(got, want) < 2e-2 and rel_err(genc, wenc) < 2e-2
 
 
-def test_fullsize_temporal_vae_decode_runs_and_is_chunk_consistent():
-    """The real VAE widths (128/256/512/512) at 576x1024: 14 frames decoded at once (2.1 GB activations at the last level),
-    finite, in range of a same-weights decode of the first 7 frames (the temporal convolutions see a different neighbourhood
-    only at the chunk border: frames 0..4 of both decodes agree closely)."""
+def test_fullsize_temporal_vae_matches_oracle_on_the_gpu():
+    """The real VAE widths (128/256/512/512): decode of a 3-frame chunk and encode of one image at 288x512 against the SAME oracle
+    modules evaluated in fp32 by torch on the GPU (the CPU oracle would need minutes per frame; at 576x1024 the fp32 torch
+    convolutions alone take 2.5 minutes), then the whole 14-frame decode at 576x1024 (BASELINE configs[3]) in one call (2.1 GB per
+    128-channel activation): finite, right shape."""
     torch.manual_seed(2)
+    ref = O.AutoencoderKLTemporalDecoder().eval()
+    state = svd_state(ref, 2)
+    ref.load_state_dict(state)
     net = AutoencoderKLTemporalDecoder().eval()
-    with torch.no_grad():
-        for n_, p_ in net.named_parameters():
-            if n_.endswith("mix_factor"):
-                p_.fill_(0.7)
+    net.load_state_dict(state)
     net = net.to("cuda", torch.float16)
-    z = torch.randn(14, 4, 72, 128, generator=torch.Generator().manual_seed(5)).cuda().half()
+    ref = ref.to("cuda")
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(14, 4, 72, 128, generator=g).cuda()
+    img = (torch.rand(1, 3, 288, 512, generator=g) * 2 - 1).cuda()
+    zs = z[:3, :, :36, :64].contiguous()
     with torch.no_grad():
-        full = net.decode(z, num_frames=14).sample
-        head = net.decode(z[:7], num_frames=7).sample
+        want = ref.decode(zs, num_frames=3).sample
+        got = net.decode(zs.half(), num_frames=3).sample
+        wenc = ref.encode(img).latent_dist.mode()
+        genc = net.encode(img.half()).latent_dist.mode()
+        full = net.decode(z.half(), num_frames=14).sample
+    assert got.shape == want.shape == (3, 3, 288, 512)
+    assert rel_err(got, want) < 3e-2 and rel_err(genc, wenc) < 3e-2
     assert full.shape == (14, 3, 576, 1024) and torch.isfinite(full).all()
-    # the temporal receptive field of the decoder is many frames deep (11 temporal res blocks + time_conv_out), so only
-    # frame 0 vs frame 0 is compared loosely; the strict check is finiteness + shape at the full size
-    assert rel_err(head[:1], full[:1]) < 0.5
 
 
 @pytest.mark.parametrize("graph", [True, False])
