@@ -247,6 +247,11 @@ class StableVideoDiffusionPipeline:
         cfg = guidance_scale is not None
         b = 2 * b0 if cfg else b0
         use_mask = mask is not None and unet.config.in_channels == 9
+        if unet.config.in_channels == 9 and mask is None:
+            raise ValueError("the UNet has the motion-mask input channel (in_channels == 9): `mask` is required")
+        n_in = (1 if use_mask else 0) + c + condition_latent.shape[2]
+        if n_in != unet.config.in_channels:
+            raise ValueError(f"mask / latents / condition latents add up to {n_in} channels, the UNet expects {unet.config.in_channels}")
         if not (self.fused_step and isinstance(sched, EulerDiscreteScheduler) and hasattr(unet, "session")):
             return self._denoise_generic(latents, image_embeddings, added_time_ids, condition_latent, mask if use_mask else None,
                                          guidance_scale, timesteps, callback)

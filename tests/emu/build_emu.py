@@ -17,7 +17,7 @@ def build(force=False):
     deps.append(os.path.join(ROOT, "include", "aa_mi355.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
-    cmd = [CLANG, "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wno-unused-value", "-Wno-psabi",
+    cmd = [CLANG, "-O2", "-mf16c", "-mavx2", "-mfma", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wno-unused-value", "-Wno-psabi",
            "-I", HERE, "-I", os.path.join(csrc, "kernels"), "-I", csrc, "-I", os.path.join(ROOT, "include"),
            "-o", out] + srcs
     subprocess.check_call(cmd)

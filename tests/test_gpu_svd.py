@@ -160,8 +160,10 @@ def test_mask_svd_pipeline_matches_oracle(graph):
     assert rel_err(got_frames, want_frames) < 5e-2
 
 
-def test_text_svd_pipeline_matches_oracle():
-    """reference models/pipeline.py:468-731, condition_type='text' (77-token context), 8-channel UNet, given condition latent."""
+@pytest.mark.parametrize("condition_type", ["text", "both"])
+def test_text_svd_pipeline_matches_oracle(condition_type):
+    """reference models/pipeline.py:468-731: condition_type='text' (77-token context) and the image + text form (:612-616,
+    78 tokens), 8-channel UNet, caller-supplied condition latent."""
     cfg = dict(SMALL_SVD_UNET, in_channels=8)
     ref_u, net_u = _pair(O.UNetSpatioTemporalConditionModel, UNetSpatioTemporalConditionModel, cfg, torch.float16)
     ref_v, net_v = _pair(O.AutoencoderKLTemporalDecoder, AutoencoderKLTemporalDecoder, SMALL_SVD_VAE, torch.float16, seed=1)
@@ -171,16 +173,20 @@ def test_text_svd_pipeline_matches_oracle():
     pe, ne = torch.randn(1, 77, 128, generator=g), torch.randn(1, 77, 128, generator=g)
     cond = torch.randn(1, f, 4, H // 8, W // 8, generator=g)
     latents = torch.randn(1, f, 4, H // 8, W // 8, generator=g)
+    clip = torch.randn(1, 1, 128, generator=g)
+    ctx = torch.cat([ne, pe])
+    if condition_type == "both":
+        ctx = torch.cat([torch.cat([torch.zeros_like(clip), clip]), ctx], dim=1)           # [uncond; cond] x (1 + 77) tokens
     with torch.no_grad():
-        want = O.svd_pipeline(ref_u, ref_v, O.EulerDiscreteScheduler(), image, torch.cat([ne, pe]), num_frames=f,
+        want = O.svd_pipeline(ref_u, ref_v, O.EulerDiscreteScheduler(), image, ctx, num_frames=f,
                               num_inference_steps=4, latents=latents.clone(), condition_latent=cond, output_type="latent",
                               min_guidance_scale=1.5, max_guidance_scale=2.5)
         pipe = TextStableVideoDiffusionPipeline(net_v, None, net_u, EulerDiscreteScheduler())
         net_u.enable_graph()
         got = pipe(image.cuda(), prompt_embeds=pe.cuda().half(), negative_prompt_embeds=ne.cuda().half(), height=H, width=W,
-                   num_frames=f, num_inference_steps=4, latents=latents.cuda(), condition_type="text",
+                   num_frames=f, num_inference_steps=4, latents=latents.cuda(), condition_type=condition_type,
                    condition_latent=cond.cuda().half(), min_guidance_scale=1.5, max_guidance_scale=2.5, output_type="latent",
-                   return_dict=False)
+                   return_dict=False, image_embeddings=clip.cuda().half())
     assert rel_err(got, want) < 3e-2
 
 
