@@ -34,6 +34,26 @@ def load_primary_models(pretrained_model_path, eval=False):
             pipeline.vae, pipeline.unet)
 
 
+def convert_svd(pretrained_model_path, out_path):
+    """reference train_svd.py:93-103: turn a plain Stable-Video-Diffusion checkpoint (8 input channels) into the motion-mask
+    form - a 9-input-channel UNet whose extra (first) input channel has zero conv_in weights, everything else copied."""
+    from .svd_unet import UNetSpatioTemporalConditionModel
+    pipeline = StableVideoDiffusionPipeline.from_pretrained(pretrained_model_path)
+    cfg = dict(vars(pipeline.unet.config), in_channels=9)
+    unet = UNetSpatioTemporalConditionModel.from_config(cfg)
+    state = {k: v for k, v in pipeline.unet.state_dict().items() if k != "conv_in.weight"}
+    missing, unexpected = unet.load_state_dict(state, strict=False)
+    assert list(missing) == ["conv_in.weight"] and not unexpected
+    with torch.no_grad():
+        unet.conv_in.weight.zero_()
+        unet.conv_in.weight[:, 1:] = pipeline.unet.conv_in.weight
+    unet.invalidate_caches()
+    new_pipeline = StableVideoDiffusionPipeline(pipeline.vae, pipeline.image_encoder, unet, pipeline.scheduler,
+                                                pipeline.feature_extractor)
+    new_pipeline.save_pretrained(out_path)
+    return new_pipeline
+
+
 def eval(pipeline, vae_processor, validation_data, out_file, index, forward_t=25, preview=True, generator=None):
     """reference train_svd.py:726-790."""
     vae = pipeline.vae

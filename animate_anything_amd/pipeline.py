@@ -87,6 +87,23 @@ class LatentToVideoPipeline:
                 pass
         return cls(vae, text_encoder, tokenizer, unet, scheduler)
 
+    def save_pretrained(self, path):
+        """diffusers directory layout (what `from_pretrained` reads; reference train.py:298-299): unet/, vae/,
+        scheduler/scheduler_config.json, text_encoder/ + tokenizer/ through transformers when present, model_index.json."""
+        os.makedirs(path, exist_ok=True)
+        index = {"_class_name": "LatentToVideoPipeline"}
+        for name in ("unet", "vae", "text_encoder", "tokenizer"):
+            m = getattr(self, name)
+            if m is not None and hasattr(m, "save_pretrained"):
+                m.save_pretrained(os.path.join(path, name))
+                index[name] = [type(m).__module__.split(".")[0], type(m).__name__]
+        os.makedirs(os.path.join(path, "scheduler"), exist_ok=True)
+        with open(os.path.join(path, "scheduler", "scheduler_config.json"), "w") as f:
+            json.dump(dict(vars(self.scheduler.config), _class_name=type(self.scheduler).__name__), f, indent=2)
+        index["scheduler"] = ["animate_anything_amd", type(self.scheduler).__name__]
+        with open(os.path.join(path, "model_index.json"), "w") as f:
+            json.dump(index, f, indent=2)
+
     def to(self, device=None, torch_dtype=None, **_):
         for m in (self.vae, self.unet, self.text_encoder):
             if m is not None:

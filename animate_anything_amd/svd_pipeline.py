@@ -143,6 +143,23 @@ class StableVideoDiffusionPipeline:
                 pass
         return cls(vae, image_encoder, unet, scheduler, feature_extractor)
 
+    def save_pretrained(self, path):
+        """diffusers directory layout (what `from_pretrained` reads; reference train_svd.py:103,320-321): unet/, vae/,
+        scheduler/scheduler_config.json, image_encoder/ + feature_extractor/ through transformers when present."""
+        os.makedirs(path, exist_ok=True)
+        index = {"_class_name": "StableVideoDiffusionPipeline"}
+        for name in ("unet", "vae", "image_encoder", "feature_extractor"):
+            m = getattr(self, name)
+            if m is not None and hasattr(m, "save_pretrained"):
+                m.save_pretrained(os.path.join(path, name))
+                index[name] = [type(m).__module__.split(".")[0], type(m).__name__]
+        os.makedirs(os.path.join(path, "scheduler"), exist_ok=True)
+        with open(os.path.join(path, "scheduler", "scheduler_config.json"), "w") as f:
+            json.dump(dict(vars(self.scheduler.config), _class_name=type(self.scheduler).__name__), f, indent=2)
+        index["scheduler"] = ["animate_anything_amd", type(self.scheduler).__name__]
+        with open(os.path.join(path, "model_index.json"), "w") as f:
+            json.dump(index, f, indent=2)
+
     def to(self, device=None, torch_dtype=None, **_):
         for m in (self.vae, self.unet, self.image_encoder):
             if m is not None:

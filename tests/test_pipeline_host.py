@@ -82,3 +82,23 @@ def test_pipeline_input_checks_and_helpers():
     assert len(fr) == 2 and fr[0].shape == (4, 10, 3) and all((a == b).all() for a, b in zip(fr, ofr))
     z = torch.randn(2, 4, 5, 3, 3)
     assert torch.allclose(calculate_latent_motion_score(z), 10 * (z[:, :, 1:] - z[:, :, :-1]).abs().mean(dim=[2, 3, 4]).sum(1))
+
+
+def test_pipeline_save_pretrained_roundtrip(tmp_path):
+    """LatentToVideoPipeline.save_pretrained writes the diffusers directory layout from_pretrained reads (reference
+    train.py:298-299, 799-804): identical weights, configs and scheduler settings after a round trip (no kernels involved)."""
+    import torch
+    from animate_anything_amd.pipeline import LatentToVideoPipeline
+    from animate_anything_amd.schedulers import DPMSolverMultistepScheduler
+    from animate_anything_amd.unet3d import UNet3DConditionModel
+    from animate_anything_amd.vae import AutoencoderKL
+    from util import TINY_UNET, TINY_VAE
+    torch.manual_seed(0)
+    pipe = LatentToVideoPipeline(vae=AutoencoderKL(**TINY_VAE), unet=UNet3DConditionModel(**TINY_UNET),
+                                 scheduler=DPMSolverMultistepScheduler(beta_end=0.013))
+    pipe.save_pretrained(str(tmp_path / "ckpt"))
+    again = LatentToVideoPipeline.from_pretrained(str(tmp_path / "ckpt"))
+    assert again.unet.config.block_out_channels == tuple(TINY_UNET["block_out_channels"]) and again.unet.motion_mask
+    assert again.scheduler.config.beta_end == 0.013 and again.vae_scale_factor == pipe.vae_scale_factor
+    for a, b in ((pipe.unet, again.unet), (pipe.vae, again.vae)):
+        assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))

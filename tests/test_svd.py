@@ -289,3 +289,33 @@ def test_svd_unet_refuses_cpu_tensors():
     _, net = tiny_unet()
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 2, 9, 4, 4).half(), 1.0, torch.zeros(1, 1, 64).half(), torch.zeros(1, 3))
+
+
+# ------------------------------------------------------------------------------------------- checkpoints (no kernels involved)
+def test_svd_pipeline_save_load_roundtrip_and_convert_svd(emu, tmp_path):
+    """save_pretrained / from_pretrained of the whole pipeline (diffusers directory layout) and the reference's `convert_svd`
+    (train_svd.py:93-103): the 9-channel UNet it builds ignores the new mask channel (zero weights) and otherwise IS the
+    8-channel model."""
+    from animate_anything_amd import eval_svd
+    from animate_anything_amd.svd_pipeline import StableVideoDiffusionPipeline
+    _, net8 = tiny_unet(in_channels=8)
+    _, vae = tiny_vae()
+    pipe = StableVideoDiffusionPipeline(vae.float(), None, net8.float(), EulerDiscreteScheduler())
+    pipe.save_pretrained(str(tmp_path / "svd8"))
+    again = StableVideoDiffusionPipeline.from_pretrained(str(tmp_path / "svd8"))
+    assert again.unet.config.in_channels == 8 and again.scheduler.config.sigma_max == 700.0
+    assert all(torch.equal(a, b) for a, b in zip(pipe.unet.state_dict().values(), again.unet.state_dict().values()))
+    assert all(torch.equal(a, b) for a, b in zip(pipe.vae.state_dict().values(), again.vae.state_dict().values()))
+    new = eval_svd.convert_svd(str(tmp_path / "svd8"), str(tmp_path / "svd9"))
+    net9 = StableVideoDiffusionPipeline.from_pretrained(str(tmp_path / "svd9")).unet
+    assert net9.config.in_channels == 9 and net9.conv_in.weight[:, 0].abs().max() == 0
+    assert torch.equal(net9.conv_in.weight[:, 1:], again.unet.conv_in.weight) and new.unet.config.in_channels == 9
+    g = torch.Generator().manual_seed(21)
+    b, f, h, w = 2, 2, 4, 6
+    x8, ctx = torch.randn(b, f, 8, h, w, generator=g), torch.randn(b, 1, 64, generator=g)
+    x9 = torch.cat([torch.rand(b, f, 1, h, w, generator=g), x8], dim=2)
+    ids = torch.tensor([[6.0, 127.0, 0.02]]).repeat(b, 1)
+    with torch.no_grad():
+        y8 = again.unet.half()(x8.half(), 0.7, ctx.half(), ids).sample
+        y9 = net9.half()(x9.half(), 0.7, ctx.half(), ids).sample
+    assert rel_err(y9, y8) < 2e-3
