@@ -14,7 +14,6 @@ reproduce the diffusers state-dict keys so one seeded state dict loads into this
 """
 from __future__ import annotations
 
-import math
 from types import SimpleNamespace
 
 import numpy as np

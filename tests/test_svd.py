@@ -8,7 +8,6 @@ import torch
 import oracle.svd as O
 from animate_anything_amd import ops
 from animate_anything_amd._lib import AA_ACT_SILU
-from animate_anything_amd.layers import Grid
 from animate_anything_amd.schedulers import EulerDiscreteScheduler
 from animate_anything_amd.svd_pipeline import (MaskStableVideoDiffusionPipeline, TextStableVideoDiffusionPipeline,
                                                _resize_with_antialiasing)
