@@ -318,3 +318,28 @@ def test_svd_pipeline_save_load_roundtrip_and_convert_svd(emu, tmp_path):
         y8 = again.unet.half()(x8.half(), 0.7, ctx.half(), ids).sample
         y9 = net9.half()(x9.half(), 0.7, ctx.half(), ids).sample
     assert rel_err(y9, y8) < 2e-3
+
+
+def test_encode_image_through_a_transformers_clip_vision_tower():
+    """`_encode_image` (diffusers StableVideoDiffusionPipeline): PIL image -> antialiased 224x224 -> CLIP normalisation -> the
+    `transformers` CLIPVisionModelWithProjection the reference loads (a tiny random-init one here) -> [uncond zeros; embedding]."""
+    from PIL import Image
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    torch.manual_seed(0)
+    cfg = CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, image_size=224,
+                           patch_size=32, projection_dim=64)
+    tower = CLIPVisionModelWithProjection(cfg).eval()
+    _, net = tiny_unet()
+    pipe = MaskStableVideoDiffusionPipeline(None, tower, net, EulerDiscreteScheduler())
+    img = Image.fromarray((np.random.default_rng(0).random((90, 160, 3)) * 255).astype(np.uint8))
+    with torch.no_grad():
+        e = pipe._encode_image(img, torch.device("cpu"), 1, True)
+        x = pipe.image_processor.preprocess(img)
+        x = (_resize_with_antialiasing(x, (224, 224)) + 1.0) / 2.0
+        mean = torch.tensor(pipe._CLIP_MEAN).reshape(1, 3, 1, 1)
+        std = torch.tensor(pipe._CLIP_STD).reshape(1, 3, 1, 1)
+        want = tower((x - mean) / std).image_embeds
+    assert e.shape == (2, 1, 64) and e[0].abs().max() == 0
+    assert torch.allclose(e[1, 0], want[0], atol=1e-6)
+    ready = torch.randn(1, 1, 64)
+    assert torch.equal(pipe._encode_image(img, torch.device("cpu"), 1, False, ready), ready)
