@@ -8,8 +8,8 @@ num_frames,width,height,num_inference_steps,guidance_scale,fps}`, `seed`, `motio
 The third-party pieces the reference pulls in and that do not exist in this image are replaced by small
 equivalents: OmegaConf -> PyYAML + dot-list merge, `VaeImageProcessor.preprocess` -> PIL lanczos resize + [-1,1]
 scaling, torchvision `ToTensor`/`Resize(antialias=False)` -> torch bilinear interpolate, imageio -> PIL GIF writer.
-`calculate_motion_precision` (OpenCV contour metric on decoded frames, utils/common.py:88-141) is outside the hot
-path and reported as nan.  If the checkpoint has no loadable CLIP text encoder, `validation_data.prompt_embeds`
+`calculate_motion_precision` (OpenCV metric on the decoded frames, utils/common.py:88-141) is restated with numpy +
+scipy.ndimage (host side, outside the hot path).  If the checkpoint has no loadable CLIP text encoder, `validation_data.prompt_embeds`
 (a .pt file with `prompt_embeds` / `negative_prompt_embeds`) may stand in for the prompt.
 """
 from __future__ import annotations
@@ -84,6 +84,40 @@ def mask_to_latent(np_mask, h, w):
     return m[:, :, None]
 
 
+def get_moved_area_mask(frames, move_th=5, th=-1):
+    """reference utils/common.py:88-133 without OpenCV: frames -> gray (cv2's 8-bit BGR2GRAY fixed-point weights on channels
+    0/1/2 - the reference hands it RGB frames as they are), |gray_0 - gray_i| > move_th accumulated over the frames, then the
+    union of the bounding rectangles of the connected regions (cv2.findContours is 8-connected; the bounding rectangle of an
+    inner contour lies inside its outer one) whose area reaches `th` (default 0.5 % of the frame)."""
+    from scipy import ndimage
+
+    def gray(f):
+        f = np.asarray(f).astype(np.int64)
+        return ((f[..., 0] * 1868 + f[..., 1] * 9617 + f[..., 2] * 4899 + 8192) >> 14).astype(np.int16)
+
+    ref = gray(frames[0])
+    total = np.zeros(ref.shape, dtype=bool)
+    for f in frames[1:]:
+        total |= np.abs(ref - gray(f)) > move_th
+    labels, _ = ndimage.label(total, structure=np.ones((3, 3), dtype=bool))
+    mask = np.zeros(ref.shape, dtype=np.uint8)
+    if th < 0:
+        th = int(mask.shape[0] * mask.shape[1] * 0.005)
+    for sl in ndimage.find_objects(labels):
+        h, w = sl[0].stop - sl[0].start, sl[1].stop - sl[1].start
+        if w * h < th:
+            continue
+        mask[sl] = 255
+    return mask
+
+
+def calculate_motion_precision(frames, mask):
+    """reference utils/common.py:136-141: share of the moved area that lies inside the motion mask."""
+    moved = get_moved_area_mask(frames, move_th=20, th=0) == 255
+    gt = np.asarray(mask) == 255
+    return float(np.sum(moved & gt) / np.sum(moved)) if moved.any() else float("nan")
+
+
 def save_gif(path, frames, fps):
     imgs = [Image.fromarray(f) for f in frames]
     imgs[0].save(path, save_all=True, append_images=imgs[1:], duration=int(1000 / fps), loop=0)
@@ -153,7 +187,7 @@ def eval(pipeline, validation_data, out_file, index, forward_t=25, preview=True,
     if preview:
         save_gif(out_file, video_frames, validation_data.get("fps", 8))
     real_motion_strength = calculate_latent_motion_score(video_latents.float()).cpu().numpy()[0]
-    precision = float("nan")
+    precision = calculate_motion_precision(video_frames, np_mask)                       # train.py:786
     print(f"save file {out_file}, motion strength {motion_strength} -> {real_motion_strength}, motion precision {precision}")
     return precision, video_frames, video_latents
 

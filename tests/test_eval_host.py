@@ -25,3 +25,31 @@ def test_image_and_mask_preprocessing():
     m[:, 48:] = 255
     lat = aa_eval.mask_to_latent(m, 8, 12)
     assert lat.shape == (1, 1, 1, 8, 12) and lat[0, 0, 0, 0, 0] == 0 and lat[0, 0, 0, 0, -1] == 1
+
+
+def test_motion_precision_metric():
+    """utils/common.py:88-141 restated without OpenCV: a square that moves inside the mask scores 1, one that moves half
+    outside scores the overlap share of its bounding rectangle, no motion gives nan."""
+    import numpy as np
+    from animate_anything_amd.eval import calculate_motion_precision, get_moved_area_mask
+    h, w = 64, 96
+    mask = np.zeros((h, w), dtype=np.uint8)
+    mask[16:48, 16:48] = 255
+
+    def frame(x0):
+        f = np.zeros((h, w, 3), dtype=np.uint8)
+        f[24:32, x0:x0 + 8] = 200
+        return f
+
+    inside = [frame(20), frame(24), frame(30)]
+    moved = get_moved_area_mask(inside, move_th=20, th=0)
+    ys, xs = np.nonzero(moved)
+    assert (ys.min(), ys.max(), xs.min(), xs.max()) == (24, 31, 20, 37)          # union of old and new positions, one rectangle
+    assert calculate_motion_precision(inside, mask) == 1.0
+    crossing = [frame(40), frame(50)]                 # two separate 8-column regions (40..47 inside the mask, 50..57 outside)
+    assert calculate_motion_precision(crossing, mask) == 0.5
+    assert np.isnan(calculate_motion_precision([frame(20), frame(20)], mask))
+    assert get_moved_area_mask(inside).max() == 255          # default area threshold: 0.5 % of the frame = 30 px <= 8 x 18
+    speck = [frame(20), frame(20).copy()]
+    speck[1][5:8, 5:8] = 255                                  # a 3 x 3 change is below it
+    assert get_moved_area_mask(speck).max() == 0 and get_moved_area_mask(speck, th=0).sum() == 9 * 255
