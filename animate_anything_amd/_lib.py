@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the dlopen below: libaa_mi355.so has t
 #                           torch already loaded, otherwise two runtimes end up in one process)
 
 AA_F16, AA_BF16, AA_F32 = 0, 1, 2
-AA_ACT_NONE, AA_ACT_SILU = 0, 1
+AA_ACT_NONE, AA_ACT_SILU, AA_ACT_GELU, AA_ACT_QUICK_GELU = 0, 1, 2, 3
 
 
 class AaConvGemm(C.Structure):
@@ -49,7 +49,7 @@ class AaAttention(C.Structure):
     _fields_ = [
         ("q", AaAttnOperand), ("k", AaAttnOperand), ("v", AaAttnOperand), ("o", AaAttnOperand),
         ("n_outer", C.c_int32), ("n_inner", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
-        ("q_len", C.c_int32), ("kv_len", C.c_int32), ("dtype", C.c_int32), ("scale", C.c_float),
+        ("q_len", C.c_int32), ("kv_len", C.c_int32), ("dtype", C.c_int32), ("scale", C.c_float), ("causal", C.c_int32), ("_pad", C.c_int32),
     ]
 
 

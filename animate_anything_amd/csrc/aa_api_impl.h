@@ -375,6 +375,7 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream) {
     if ((int64_t)d->n_img * d->h_out * d->w_out >= (int64_t)1 << 31) return fail(AA_E_SHAPE, "conv_gemm: M overflows int32");
     if (!aligned16(d->a0) || !aligned16(d->a1) || !aligned16(d->w)) return fail(AA_E_ALIGN, "conv_gemm: operands must be 16-byte aligned");
     if (d->out_dtype != AA_F32 && d->out_dtype != d->dtype) return fail(AA_E_DTYPE, "conv_gemm: out_dtype must be dtype or f32");
+    if (d->act != AA_ACT_NONE && d->act != AA_ACT_SILU) return fail(AA_E_SHAPE, "conv_gemm: activation %d is not fused here (AA_ACT_NONE / AA_ACT_SILU)", d->act);
     if (d->dtype == AA_F16) return conv_gemm_t<f16_t>(*d, stream);
     if (d->dtype == AA_BF16) return conv_gemm_t<bf16_t>(*d, stream);
     return fail(AA_E_DTYPE, "conv_gemm: unsupported dtype %d", d->dtype);
@@ -428,6 +429,7 @@ int aa_attention(const AaAttention* d, void* stream) {
         if (x->seq_mod < 0) return fail(AA_E_SHAPE, "attention: seq_mod must be >= 0");
     }
     if (d->q.seq_mod || d->o.seq_mod) return fail(AA_E_SHAPE, "attention: seq_mod addressing is for K / V only");
+    if (d->causal && d->head_dim != 64) return fail(AA_E_SHAPE, "attention: causal masking is implemented for head_dim 64");
     // K / V are read through buffer descriptors with 32-bit byte offsets; offsets >= 2^31 mean "zero"
     if (d->head_dim == 64 && (attn_extent_bytes(d->k, d->n_outer, d->n_inner, d->kv_len) >= ((int64_t)1 << 31) ||
         attn_extent_bytes(d->v, d->n_outer, d->n_inner, d->kv_len) >= ((int64_t)1 << 31)))
@@ -503,6 +505,7 @@ int aa_cfg_dpm_step_tokens(const AaDpmStepTok* d, void* stream) {
 int aa_blend(const AaBlend* d, void* stream) {
     using namespace aa;
     if (!d || !d->x || !d->out) return fail(AA_E_SHAPE, "blend: null operand");
+    if (d->act < AA_ACT_NONE || d->act > AA_ACT_QUICK_GELU) return fail(AA_E_SHAPE, "blend: unknown activation %d", d->act);
     if (d->rows <= 0 || d->channels <= 0 || d->channels % 8 || (d->rowvec && d->rowvec_div <= 0) || d->rowvec_mod < 0 ||
         (d->rowvec_ld && d->rowvec_ld < d->channels) || d->rowvec_ld % 8)
         return fail(AA_E_SHAPE, "blend: bad geometry (rows=%lld channels=%d)", (long long)d->rows, d->channels);

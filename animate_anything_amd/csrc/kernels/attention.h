@@ -166,6 +166,16 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) atte
                     const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + kb * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
                     sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], sacc[kb]);
                 }
+            if (p.causal && kt * KT + KT - 1 > q0) {     // causal: keys after the query's own position (tiles that reach past the wave's first query)
+                const int qpos = q0 + ql;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = kt * KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (key > qpos) sacc[kb][e] = -1.0e30f;
+                    }
+            }
             if (ragged && kt == ntiles - 1) {           // mask the keys past kv_len (last tile only)
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)

@@ -8,6 +8,7 @@
 #pragma once
 #include "dev.h"
 #include "aa_mi355.h"
+#include "conv_gemm.h"      // silu_f, gelu_erf_f
 
 namespace aa {
 
@@ -116,6 +117,12 @@ __global__ void __launch_bounds__(256) blend_kernel(const AaBlend p) {
         if (p.act == AA_ACT_SILU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        } else if (p.act == AA_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+        } else if (p.act == AA_ACT_QUICK_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.e[e] = (T)v[e];

@@ -133,7 +133,8 @@ def load_primary_models(pretrained_model_path, motion_mask=None, motion_strength
     noise_scheduler = DDPMScheduler(**{k: v for k, v in scfg.items() if not k.startswith("_")})
     tokenizer = text_encoder = None
     try:
-        from transformers import CLIPTextModel, CLIPTokenizer
+        from transformers import CLIPTokenizer
+        from .clip import CLIPTextModel
         tokenizer = CLIPTokenizer.from_pretrained(pretrained_model_path, subfolder="tokenizer")
         text_encoder = CLIPTextModel.from_pretrained(pretrained_model_path, subfolder="text_encoder")
     except Exception:

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (AA_ACT_NONE, AA_ACT_SILU, AA_BF16, AA_F16, AA_F32, AaAttention, AaAttnOperand,
+from ._lib import (AA_ACT_GELU, AA_ACT_NONE, AA_ACT_QUICK_GELU, AA_ACT_SILU, AA_BF16, AA_F16, AA_F32, AaAttention, AaAttnOperand,
                    AaBlend, AaConvGemm, AaDpmStep, AaDpmStepTok, AaEulerStepTok, AaGroupNorm, AaPackFrames, AaPackLatents)
 
 _DT = {torch.float16: AA_F16, torch.bfloat16: AA_BF16, torch.float32: AA_F32}
@@ -448,7 +448,7 @@ def _operand(t: torch.Tensor, col0: int, outer_stride: int, inner_stride: int, p
 def attention(q: torch.Tensor, q_col0: int, k: torch.Tensor, k_col0: int, v: torch.Tensor, v_col0: int,
               heads: int, n_outer: int, n_inner: int, q_len: int, kv_len: int,
               q_strides, kv_strides, kv_outer_div: int = 1, scale: Optional[float] = None, head_dim: int = 64,
-              kv_seq_mod: int = 0) -> torch.Tensor:
+              kv_seq_mod: int = 0, causal: bool = False) -> torch.Tensor:
     """softmax(q k^T * scale) v for every (outer, inner, head).  `*_strides` = (outer, inner, pos)
     row strides of the token matrices; output rows use the q addressing, columns [0, heads*64)."""
     lib = _lib.get()
@@ -462,6 +462,7 @@ def attention(q: torch.Tensor, q_col0: int, k: torch.Tensor, k_col0: int, v: tor
     d.v = _operand(v, v_col0, *kv_strides, outer_div=kv_outer_div)
     d.o = _operand(out, 0, *q_strides)
     d.k.seq_mod = d.v.seq_mod = kv_seq_mod       # > 0: sequence number n reads K / V table entry n % kv_seq_mod
+    d.causal = int(causal)                       # key position > query position masked (CLIP text encoder)
     d.n_outer, d.n_inner, d.heads, d.head_dim = n_outer, n_inner, heads, head_dim
     d.q_len, d.kv_len, d.dtype = q_len, kv_len, _DT[q.dtype]
     d.scale = float(head_dim) ** -0.5 if scale is None else scale

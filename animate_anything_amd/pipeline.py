@@ -79,8 +79,9 @@ class LatentToVideoPipeline:
             cfg = json.load(open(cfg_path)) if os.path.exists(cfg_path) else {}
             scheduler = DPMSolverMultistepScheduler.from_config(cfg)
         if tokenizer is None or text_encoder is None:
-            try:
-                from transformers import CLIPTextModel, CLIPTokenizer
+            try:                   # the tokenizer is transformers' (host-side string processing), the text tower is clip.py
+                from transformers import CLIPTokenizer
+                from .clip import CLIPTextModel
                 tokenizer = tokenizer or CLIPTokenizer.from_pretrained(path, subfolder="tokenizer")
                 text_encoder = text_encoder or CLIPTextModel.from_pretrained(path, subfolder="text_encoder")
             except Exception:      # text encoder is optional: callers may pass prompt_embeds

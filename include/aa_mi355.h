@@ -32,7 +32,8 @@ extern "C" {
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
-enum { AA_ACT_NONE = 0, AA_ACT_SILU = 1 };
+enum { AA_ACT_NONE = 0, AA_ACT_SILU = 1,
+       AA_ACT_GELU = 2, AA_ACT_QUICK_GELU = 3 /* aa_blend only: erf GELU / x*sigmoid(1.702 x) (CLIP MLP, transformers hidden_act) */ };
 
 int aa_version(void);
 const char* aa_last_error(void);
@@ -174,6 +175,9 @@ typedef struct AaAttention {
     int32_t q_len, kv_len;
     int32_t dtype;
     float scale;
+    int32_t causal;    /* 1: key position > query position is masked (the CLIP text encoder's causal attention, transformers
+                          CLIPTextModel - reference train.py:88); head_dim 64 only.  0: none (every attention of the UNets) */
+    int32_t _pad;
 } AaAttention;
 
 int aa_attention(const AaAttention* d, void* stream);

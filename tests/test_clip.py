@@ -1,0 +1,76 @@
+"""CLIP text encoder (reference train.py:88) against its REAL reference: `transformers.CLIPTextModel`
+is installed in the build container, so this component's parity is pinned to the dependency itself, not to a restatement."""
+import pytest
+import torch
+
+from animate_anything_amd.clip import CLIPTextModel
+
+TINY_CLIP = dict(vocab_size=120, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                 max_position_embeddings=24)
+
+
+def _pair(act, eos=2, **over):
+    from transformers import CLIPTextConfig
+    from transformers import CLIPTextModel as HFCLIPTextModel
+    torch.manual_seed(0)
+    cfg = dict(TINY_CLIP, hidden_act=act, eos_token_id=eos, **over)
+    ref = HFCLIPTextModel(CLIPTextConfig(**cfg, bos_token_id=0, pad_token_id=1)).eval()
+    net = CLIPTextModel(**cfg).eval()
+    # transformers 4.36 (the reference's pin) and the checkpoints on disk carry a `text_model.` level, transformers >= 5 does not
+    state = {(k if k.startswith("text_model.") else "text_model." + k): v for k, v in ref.state_dict().items()}
+    assert set(net.state_dict().keys()) == {k for k in state if not k.endswith("position_ids")}
+    net.load_state_dict(state)
+    return ref, net
+
+
+@pytest.mark.parametrize("act,eos", [("gelu", 2), ("quick_gelu", 119)])
+def test_tiny_clip_text_model_matches_transformers(emu, act, eos):
+    ref, net = _pair(act, eos)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(3, 118, (2, 24), generator=g)
+    ids[:, 0] = 0
+    ids[0, 9], ids[1, 17] = 119, 119                      # end-of-text token (also the largest id: both pooling conventions)
+    with torch.no_grad():
+        want = ref(ids)
+        got = net.half()(ids)
+    assert got[0].shape == want.last_hidden_state.shape == (2, 24, 128)
+    err = (got[0].float() - want.last_hidden_state).abs().max() / want.last_hidden_state.abs().max()
+    assert err < 1e-2
+    assert torch.allclose(got.pooler_output.float(), want.pooler_output, atol=3e-2)
+    assert torch.equal(got.last_hidden_state, got[0])
+
+
+def test_clip_text_model_checkpoint_roundtrip_and_guards(tmp_path):
+    ref, net = _pair("gelu")
+    net.save_pretrained(str(tmp_path / "text_encoder"))
+    again = CLIPTextModel.from_pretrained(str(tmp_path), subfolder="text_encoder")
+    assert again.config.num_hidden_layers == 2 and all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), again.state_dict().values()))
+    ref.save_pretrained(str(tmp_path / "hf"))             # a checkpoint written by transformers loads too
+    from_hf = CLIPTextModel.from_pretrained(str(tmp_path / "hf"))
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), from_hf.state_dict().values()))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 5, dtype=torch.long))          # CPU tensors: no fallback
+    with pytest.raises(ValueError):
+        CLIPTextModel(hidden_size=96, num_attention_heads=2)
+    with pytest.raises(ValueError):
+        CLIPTextModel(hidden_act="relu")
+
+
+def test_lora_folds_into_the_native_text_encoder_in_transformers_order(emu):
+    """The reference's text-encoder LoRA files list adapters in module-traversal order of transformers' CLIPEncoderLayer
+    (k, v, q, out_proj, fc1, fc2 - utils/lora.py): folding them into the native modules must hit the same layers."""
+    import oracle.lora as olora
+    from animate_anything_amd import lora as L
+    from test_lora import make_loras
+    ref, net = _pair("gelu")
+    targets_ref = L._candidates(ref, L.TEXT_ENCODER_REPLACE)
+    targets_net = L._candidates(net, L.TEXT_ENCODER_REPLACE)
+    order = ["k_proj", "v_proj", "q_proj", "out_proj", "fc1", "fc2"] * 2
+    assert [n.split(".")[-1] for n, _ in targets_net] == order and [n.split(".")[-1] for n, _ in targets_ref] == order
+    loras = make_loras(targets_ref, r=3)
+    L.fold_lora_(net, loras, L.TEXT_ENCODER_REPLACE, mode="all")
+    olora.inject(ref, [n for n, _ in targets_ref], loras)
+    ids = torch.randint(3, 118, (2, 12), generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        want, got = ref(ids)[0], net.half()(ids)[0]
+    assert (got.float() - want).abs().max() / want.abs().max() < 1e-2

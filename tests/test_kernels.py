@@ -169,6 +169,19 @@ def test_attention_spatial(backend):
     close(o, ref, tol=1e-2)
 
 
+@pytest.mark.parametrize("L", [77, 20, 300])
+def test_attention_causal(backend, L):
+    """AaAttention.causal (the CLIP text encoder): key position > query position masked - one tile, the 32-key tile of short
+    sequences, several tiles through the ring (later tiles fully masked for the first queries)."""
+    n, heads = 2, 2
+    C = heads * 64
+    qkv = rnd(n * L, 3 * C, seed=33)
+    o = ops.attention(qkv, 0, qkv, C, qkv, 2 * C, heads, n, 1, L, L, (L, 0, 1), (L, 0, 1), causal=True)
+    x = qkv.float().cpu().reshape(n, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(x[0], x[1], x[2], is_causal=True).permute(0, 2, 1, 3).reshape(n * L, C)
+    close(o, ref, tol=1e-2)
+
+
 @pytest.mark.parametrize("Lq,Lkv", [(300, 300), (50, 200), (130, 64)])
 def test_attention_ring(backend, Lq, Lkv):
     """Several K/V tiles through the 3-slot LDS ring (4-wave and 1-wave workgroups), ragged last tile, single tile."""
