@@ -313,9 +313,11 @@ static int gn_chunks(const AaGroupNorm& d) {
 template <typename T>
 static int attention_t(const AaAttention& d, void* stream) {
     const int nseq = d.n_outer * d.n_inner;
-    if (d.head_dim == 8) {
+    if (d.head_dim == 8 || d.head_dim == 80) {
         const dim3 grid((d.q_len + 255) / 256, d.heads, nseq);
-        AA_LAUNCH((attention_d8_kernel<T>), grid, dim3(256), 2 * 256 * 8 * sizeof(T), stream, d);
+        const size_t lds = (size_t)2 * 256 * d.head_dim * sizeof(T);
+        if (d.head_dim == 8) AA_LAUNCH((attention_small_kernel<T, 8>), grid, dim3(256), lds, stream, d);
+        else                 AA_LAUNCH((attention_small_kernel<T, 80>), grid, dim3(256), lds, stream, d);
         return finish("attention");
     }
     if (d.q_len > 64) {
@@ -420,7 +422,7 @@ int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y, in
 int aa_attention(const AaAttention* d, void* stream) {
     using namespace aa;
     if (!d) return fail(AA_E_SHAPE, "attention: null descriptor");
-    if (d->head_dim != 64 && d->head_dim != 8) return fail(AA_E_SHAPE, "attention: head_dim must be 64 or 8 (got %d)", d->head_dim);
+    if (d->head_dim != 64 && d->head_dim != 8 && d->head_dim != 80) return fail(AA_E_SHAPE, "attention: head_dim must be 64, 8 or 80 (got %d)", d->head_dim);
     if (d->q_len <= 0 || d->kv_len <= 0 || d->heads <= 0 || d->n_outer <= 0 || d->n_inner <= 0) return fail(AA_E_SHAPE, "attention: bad lengths");
     const AaAttnOperand* ops[4] = {&d->q, &d->k, &d->v, &d->o};
     for (const AaAttnOperand* x : ops) {

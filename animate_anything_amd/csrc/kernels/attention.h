@@ -271,45 +271,54 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) atte
 }
 
 
-// ---- attention for head_dim 8 (the layerdiffuse alpha decoder UNet384: 32 heads of 8 channels at 256 channels;
-// reference models/layerdiffuse_VAE.py:58 `attention_head_dim = 8`).  Two MFMA k-slices would be 3/4 padding at d = 8,
-// so this one runs on the vector ALUs: a thread owns one query (q, the running max / sum and the 8 outputs in registers),
-// a workgroup of 256 queries shares 256-key K / V tiles through LDS (every lane reads the SAME key row: an LDS broadcast).
-// Same operand addressing as the head_dim-64 kernel.
-template <typename T>
-__global__ void __launch_bounds__(256) attention_d8_kernel(const AaAttention p) {
-    constexpr int KT = 256;
-    T* sK = reinterpret_cast<T*>(dyn_smem());                   // [KT][8]
-    T* sV = sK + KT * 8;
+// ---- attention on the vector ALUs for the head sizes the matrix-core kernel does not cover: head_dim 8 (the layerdiffuse
+// alpha decoder UNet384: 32 heads of 8 channels at 256 channels; reference models/layerdiffuse_VAE.py:58 - two MFMA k-slices
+// would be 3/4 padding at d = 8) and head_dim 80 (the CLIP ViT-H/14 vision tower of the SVD path, 16 heads at 1280 channels,
+// 257 tokens, once per clip).  A thread owns one query (q, the running max / sum and the D outputs in registers), a workgroup
+// of 256 queries shares 256-key K / V tiles through LDS (every lane reads the SAME key row: an LDS broadcast).  Same operand
+// addressing as the head_dim-64 kernel.
+template <typename T, int D>
+__global__ void __launch_bounds__(256) attention_small_kernel(const AaAttention p) {
+    constexpr int KT = 256, DC = D / 8;
+    static_assert(D % 8 == 0, "head_dim");
+    T* sK = reinterpret_cast<T*>(dyn_smem());                   // [KT][D]
+    T* sV = sK + KT * D;
     const int tid = threadIdx.x;
     const int head = blockIdx.y, seq = blockIdx.z;
     const int o = seq / p.n_inner, i = seq - o * p.n_inner;
     const int q = blockIdx.x * 256 + tid;
     const bool active = q < p.q_len;
     const float sl2e = p.scale * 1.4426950408889634f;
-    float qv[8], acc[8];
+    float qv[D], acc[D];
     {
-        Pack8<T> raw;
-        raw.raw = u32x4{0u, 0u, 0u, 0u};
-        if (active) raw.raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.q.ptr) +
-                                  (attn_seq_row(p.q, o, i, p.n_inner) + (int64_t)q * p.q.pos_stride) * p.q.ld + p.q.col0 + head * 8);
+        const T* qrow = reinterpret_cast<const T*>(p.q.ptr) +
+                        (attn_seq_row(p.q, o, i, p.n_inner) + (int64_t)(active ? q : 0) * p.q.pos_stride) * p.q.ld + p.q.col0 + head * D;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { qv[d] = (float)raw.e[d] * sl2e; acc[d] = 0.0f; }
+        for (int c8 = 0; c8 < DC; ++c8) {
+            Pack8<T> raw;
+            raw.raw = u32x4{0u, 0u, 0u, 0u};
+            if (active) raw.raw = *reinterpret_cast<const u32x4*>(qrow + c8 * 8);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { qv[c8 * 8 + d] = (float)raw.e[d] * sl2e; acc[c8 * 8 + d] = 0.0f; }
+        }
     }
     float m_run = -1.0e30f, l_run = 0.0f;
     for (int k0 = 0; k0 < p.kv_len; k0 += KT) {
         __syncthreads();                                          // the previous tile has been consumed
         {
             const int key = k0 + tid;
-            u32x4 kr = {0u, 0u, 0u, 0u}, vr = {0u, 0u, 0u, 0u};
-            if (key < p.kv_len) {
-                kr = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.k.ptr) +
-                         (attn_seq_row(p.k, o, i, p.n_inner) + (int64_t)key * p.k.pos_stride) * p.k.ld + p.k.col0 + head * 8);
-                vr = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.v.ptr) +
-                         (attn_seq_row(p.v, o, i, p.n_inner) + (int64_t)key * p.v.pos_stride) * p.v.ld + p.v.col0 + head * 8);
+            const bool ok = key < p.kv_len;
+            const T* krow = reinterpret_cast<const T*>(p.k.ptr) +
+                            (attn_seq_row(p.k, o, i, p.n_inner) + (int64_t)(ok ? key : 0) * p.k.pos_stride) * p.k.ld + p.k.col0 + head * D;
+            const T* vrow = reinterpret_cast<const T*>(p.v.ptr) +
+                            (attn_seq_row(p.v, o, i, p.n_inner) + (int64_t)(ok ? key : 0) * p.v.pos_stride) * p.v.ld + p.v.col0 + head * D;
+#pragma unroll
+            for (int c8 = 0; c8 < DC; ++c8) {
+                u32x4 kr = {0u, 0u, 0u, 0u}, vr = {0u, 0u, 0u, 0u};
+                if (ok) { kr = *reinterpret_cast<const u32x4*>(krow + c8 * 8); vr = *reinterpret_cast<const u32x4*>(vrow + c8 * 8); }
+                *reinterpret_cast<u32x4*>(sK + tid * D + c8 * 8) = kr;
+                *reinterpret_cast<u32x4*>(sV + tid * D + c8 * 8) = vr;
             }
-            *reinterpret_cast<u32x4*>(sK + tid * 8) = kr;
-            *reinterpret_cast<u32x4*>(sV + tid * 8) = vr;
         }
         __syncthreads();
         const int n = min(KT, p.kv_len - k0);
@@ -318,10 +327,13 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AaAttention p) 
             float cmax = -1.0e30f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                Pack8<T> kr; kr.raw = *reinterpret_cast<const u32x4*>(sK + (j + e) * 8);
                 float d = 0.0f;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) d = __builtin_fmaf(qv[c], (float)kr.e[c], d);
+                for (int c8 = 0; c8 < DC; ++c8) {
+                    Pack8<T> kr; kr.raw = *reinterpret_cast<const u32x4*>(sK + (j + e) * D + c8 * 8);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) d = __builtin_fmaf(qv[c8 * 8 + c], (float)kr.e[c], d);
+                }
                 s[e] = (j + e < n) ? d : -1.0e30f;
                 cmax = fmaxf(cmax, s[e]);
             }
@@ -329,26 +341,33 @@ __global__ void __launch_bounds__(256) attention_d8_kernel(const AaAttention p) 
                 const float alpha = fast_exp2(m_run - cmax);
                 l_run *= alpha;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] *= alpha;
+                for (int c = 0; c < D; ++c) acc[c] *= alpha;
                 m_run = cmax;
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float pe = fast_exp2(s[e] - m_run);
                 l_run += pe;
-                Pack8<T> vr; vr.raw = *reinterpret_cast<const u32x4*>(sV + (j + e) * 8);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] = __builtin_fmaf(pe, (float)vr.e[c], acc[c]);
+                for (int c8 = 0; c8 < DC; ++c8) {
+                    Pack8<T> vr; vr.raw = *reinterpret_cast<const u32x4*>(sV + (j + e) * D + c8 * 8);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c8 * 8 + c] = __builtin_fmaf(pe, (float)vr.e[c], acc[c8 * 8 + c]);
+                }
             }
         }
     }
     if (active) {
         const float inv = 1.0f / l_run;
-        Pack8<T> out;
+        T* orow = reinterpret_cast<T*>(const_cast<void*>(p.o.ptr)) +
+                  (attn_seq_row(p.o, o, i, p.n_inner) + (int64_t)q * p.o.pos_stride) * p.o.ld + p.o.col0 + head * D;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) out.e[c] = (T)(acc[c] * inv);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(const_cast<void*>(p.o.ptr)) +
-            (attn_seq_row(p.o, o, i, p.n_inner) + (int64_t)q * p.o.pos_stride) * p.o.ld + p.o.col0 + head * 8) = out.raw;
+        for (int c8 = 0; c8 < DC; ++c8) {
+            Pack8<T> out;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) out.e[c] = (T)(acc[c8 * 8 + c] * inv);
+            *reinterpret_cast<u32x4*>(orow + c8 * 8) = out.raw;
+        }
     }
 }
 

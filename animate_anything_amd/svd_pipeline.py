@@ -8,7 +8,8 @@ Same keyword arguments and return convention.  Per denoising step the device wor
 replay holding the embeddings, the input assembly `cat([mask, latents / sqrt(sigma^2+1), image_latents], dim=2)` and the
 whole forward) and one fused per-frame-guidance + Euler update kernel (`aa_cfg_euler_step_tokens`), which also deposits
 the next step's timestep and input scale - the reference's cat / scale_model_input / chunk / scheduler.step chain
-(pipeline.py:417-440) collapses into those two.  The CLIP image encoder stays the `transformers` module the reference uses.
+(pipeline.py:417-440) collapses into those two.  The CLIP image encoder is `clip.CLIPVisionModelWithProjection` (a `transformers`
+module passed by the caller works as well).
 """
 from __future__ import annotations
 
@@ -123,7 +124,7 @@ class StableVideoDiffusionPipeline:
 
     @classmethod
     def from_pretrained(cls, path, torch_dtype=None, variant=None, vae=None, unet=None, image_encoder=None, scheduler=None, **_):
-        """diffusers directory layout (reference train_svd.py:85-91).  The CLIP vision tower is loaded through transformers."""
+        """diffusers directory layout (reference train_svd.py:85-91)."""
         from .svd_unet import UNetSpatioTemporalConditionModel
         from .svd_vae import AutoencoderKLTemporalDecoder
         if unet is None:
@@ -133,12 +134,11 @@ class StableVideoDiffusionPipeline:
         if scheduler is None:
             cfg_path = os.path.join(path, "scheduler", "scheduler_config.json")
             scheduler = EulerDiscreteScheduler.from_config(json.load(open(cfg_path)) if os.path.exists(cfg_path) else {})
-        feature_extractor = None
+        feature_extractor = None   # (`_encode_image` applies the CLIP resize / normalisation itself)
         if image_encoder is None:
             try:
-                from transformers import CLIPImageProcessor, CLIPVisionModelWithProjection
+                from .clip import CLIPVisionModelWithProjection
                 image_encoder = CLIPVisionModelWithProjection.from_pretrained(path, subfolder="image_encoder", torch_dtype=torch_dtype)
-                feature_extractor = CLIPImageProcessor.from_pretrained(path, subfolder="feature_extractor")
             except Exception:      # optional: callers may pass image_embeddings
                 pass
         return cls(vae, image_encoder, unet, scheduler, feature_extractor)

@@ -149,13 +149,14 @@ int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y,
                  int64_t rows, int32_t channels, float eps, int32_t dtype, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
- * aa_attention: O = softmax(Q K^T * scale) V per (sequence, head), head_dim 64 (matrix cores) or 8 (vector
+ * aa_attention: O = softmax(Q K^T * scale) V per (sequence, head), head_dim 64 (matrix cores) or 8 / 80 (vector
  * ALUs: the 32-head x 8-channel attention of the layerdiffuse alpha decoder, reference
- * models/layerdiffuse_VAE.py:58), flash-style (scores never leave the chip).  Replaces F.scaled_dot_product_attention as selected by the
+ * models/layerdiffuse_VAE.py:58; the 16-head x 80-channel CLIP ViT-H/14 vision tower of the SVD path, once per clip),
+ * flash-style (scores never leave the chip).  Replaces F.scaled_dot_product_attention as selected by the
  * reference's AttnProcessor2_0 (train.py:124-138).
  * A sequence is addressed as (outer o, inner i); the row of position p in operand X is
  *     (o / X.outer_div) * X.outer_stride + i * X.inner_stride + p * X.pos_stride      [tokens]
- * and element (head h, d) sits at column X.col0 + h*64 + d of a row of X.ld elements:
+ * and element (head h, d) sits at column X.col0 + h*head_dim + d of a row of X.ld elements:
  *   spatial self-attention   outer = image, inner = 1,      pos_stride = 1
  *   temporal self-attention  outer = clip,  inner = pixel,  pos_stride = H*W  (no permute copies)
  *   text cross-attention     K/V outer_div = frames per clip (text K/V computed once per clip)

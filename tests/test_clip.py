@@ -74,3 +74,29 @@ def test_lora_folds_into_the_native_text_encoder_in_transformers_order(emu):
     with torch.no_grad():
         want, got = ref(ids)[0], net.half()(ids)[0]
     assert (got.float() - want).abs().max() / want.abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("heads,act", [(2, "gelu"), (1, "quick_gelu")])
+def test_tiny_clip_vision_tower_matches_transformers(emu, heads, act):
+    """The SVD path's image encoder against `transformers.CLIPVisionModelWithProjection` itself: head_dim 80 (the ViT-H/14 head
+    size, vector-ALU attention kernel) and head_dim 64 (ViT-L/14, matrix-core kernel), 14x14 patch embedding, class token."""
+    from transformers import CLIPVisionConfig
+    from transformers import CLIPVisionModelWithProjection as HFVision
+    from animate_anything_amd.clip import CLIPVisionModelWithProjection
+    torch.manual_seed(0)
+    width = 160 if heads == 2 else 64
+    cfg = dict(hidden_size=width, intermediate_size=2 * width, num_hidden_layers=2, num_attention_heads=heads, image_size=42,
+               patch_size=14, projection_dim=48, hidden_act=act)
+    ref = HFVision(CLIPVisionConfig(**cfg)).eval()
+    net = CLIPVisionModelWithProjection(**cfg).eval()
+    assert set(net.state_dict().keys()) == {k for k in ref.state_dict() if not k.endswith("position_ids")}
+    net.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 3, 42, 42, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        want = ref(x)
+        got = net.half()(x)
+    assert got.image_embeds.shape == want.image_embeds.shape == (2, 48)
+    assert (got.image_embeds.float() - want.image_embeds).abs().max() / want.image_embeds.abs().max() < 1e-2
+    assert (got.last_hidden_state.float() - want.last_hidden_state).abs().max() / want.last_hidden_state.abs().max() < 1e-2
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 28, 28).half())

@@ -34,3 +34,27 @@ def test_clip_text_model_matches_transformers(name, cfg, dtype):
     assert got.shape == (2, 77, cfg["hidden_size"]) and err < (2e-2 if dtype == torch.float16 else 1e-1), err
     mse = ((got.float().cpu() - want) ** 2).mean().item() / (want ** 2).mean().item()
     assert mse < (1e-4 if dtype == torch.float16 else 1e-2), mse
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("vit-h-14", dict(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=16, projection_dim=1024, hidden_act="gelu")),
+    ("vit-l-14", dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, projection_dim=768, hidden_act="quick_gelu")),
+])
+def test_clip_vision_tower_matches_transformers(name, cfg):
+    """The SVD path's image encoder (`CLIPVisionModelWithProjection`, ViT-H/14: 16 heads of 80 channels -> the vector-ALU
+    attention kernel; ViT-L/14: heads of 64 -> the matrix-core kernel) against transformers itself, 224x224 input."""
+    from transformers import CLIPVisionConfig
+    from transformers import CLIPVisionModelWithProjection as HFVision
+    from animate_anything_amd.clip import CLIPVisionModelWithProjection
+    torch.manual_seed(0)
+    cfg = dict(cfg, image_size=224, patch_size=14)
+    ref = HFVision(CLIPVisionConfig(**cfg)).eval()
+    net = CLIPVisionModelWithProjection(**cfg).eval()
+    net.load_state_dict(ref.state_dict())
+    net = net.to("cuda", torch.float16)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        want = ref(x).image_embeds
+        got = net(x.cuda()).image_embeds
+    err = ((got.float().cpu() - want).abs().max() / want.abs().max()).item()
+    assert got.shape == (2, cfg["projection_dim"]) and err < 2e-2, err
