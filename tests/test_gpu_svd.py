@@ -219,13 +219,16 @@ def test_svd_glue_kernels_at_the_real_shapes():
 
 def test_svd_eval_driver_roundtrip(tmp_path):
     """`train_svd.py --eval` flow (train_svd.py:726-826): synthetic diffusers-layout checkpoint -> from_pretrained -> image +
-    `_label.jpg` motion mask -> MaskStableVideoDiffusionPipeline -> gif."""
+    `_label.jpg` motion mask -> CLIP image embedding (vision tower from the checkpoint) -> MaskStableVideoDiffusionPipeline -> gif."""
     from animate_anything_amd import eval_svd
     torch.manual_seed(0)
     ckpt = tmp_path / "svd"
     unet = UNetSpatioTemporalConditionModel(**SMALL_SVD_UNET)
     unet.save_pretrained(str(ckpt / "unet"))
     AutoencoderKLTemporalDecoder(**SMALL_SVD_VAE).save_pretrained(str(ckpt / "vae"))
+    from animate_anything_amd.clip import CLIPVisionModelWithProjection
+    CLIPVisionModelWithProjection(hidden_size=128, intermediate_size=256, projection_dim=128, num_hidden_layers=2,
+                                  num_attention_heads=2).save_pretrained(str(ckpt / "image_encoder"))
     os.makedirs(ckpt / "scheduler")
     json.dump({"_class_name": "EulerDiscreteScheduler", "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear",
                "num_train_timesteps": 1000, "prediction_type": "v_prediction", "use_karras_sigmas": True, "sigma_min": 0.002,
@@ -238,9 +241,8 @@ def test_svd_eval_driver_roundtrip(tmp_path):
     m = np.zeros((150, 200), dtype=np.uint8)
     m[40:110, 50:150] = 255
     Image.fromarray(m).save(tmp_path / "img_label.jpg")
-    torch.save(torch.randn(1, 1, 128), tmp_path / "clip.pt")
     cfg = {"pretrained_model_path": str(ckpt), "seed": 3, "output_dir": str(tmp_path / "out"), "iters": 2,
-           "validation_data": {"prompt_image": str(tmp_path / "img.jpg"), "prompt": "", "image_embeddings": str(tmp_path / "clip.pt"),
+           "validation_data": {"prompt_image": str(tmp_path / "img.jpg"), "prompt": "",
                                "width": 192, "height": 128, "num_frames": 4, "num_inference_steps": 25, "decode_chunk_size": 2,
                                "fps": 7, "motion_bucket_id": 127}}
     yaml.safe_dump(cfg, open(tmp_path / "svd.yaml", "w"))
