@@ -169,6 +169,19 @@ def test_attention_spatial(backend):
     close(o, ref, tol=1e-2)
 
 
+@pytest.mark.parametrize("Lq,Lkv,causal", [(1100, 1100, False), (1024, 200, False), (1030, 1030, True)])
+def test_attention_long_sequences(backend, Lq, Lkv, causal):
+    """More than a thousand queries: ragged last workgroup / wave / key tile, cross lengths, causal masking across many tiles."""
+    n, heads = 1, 2
+    q = rnd(n * Lq, heads * 64, seed=41)
+    kv = rnd(n * Lkv, 2 * heads * 64, seed=42)
+    o = ops.attention(q, 0, kv, 0, kv, heads * 64, heads, n, 1, Lq, Lkv, (Lq, 0, 1), (Lkv, 0, 1), causal=causal)
+    qq = q.float().cpu().reshape(n, Lq, heads, 64).transpose(1, 2)
+    kk = kv.float().cpu().reshape(n, Lkv, 2, heads, 64)
+    ref = F.scaled_dot_product_attention(qq, kk[:, :, 0].transpose(1, 2), kk[:, :, 1].transpose(1, 2), is_causal=causal)
+    close(o, ref.transpose(1, 2).reshape(n * Lq, heads * 64), tol=1e-2)
+
+
 @pytest.mark.parametrize("L", [77, 20, 300])
 def test_attention_causal(backend, L):
     """AaAttention.causal (the CLIP text encoder): key position > query position masked - one tile, the 32-key tile of short
