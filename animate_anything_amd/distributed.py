@@ -62,3 +62,32 @@ def gather_clips(local: torch.Tensor, num_clips: int, rank: int, world: int) -> 
     # out[r, j] is clip r + j*world
     order = out.transpose(0, 1).reshape((per * world,) + tuple(local.shape[1:]))
     return order[:num_clips].contiguous()
+
+
+# ----------------------------------------------------------------------------------------- guidance-parallel (latency) mode
+_pair_groups = {}
+
+
+def guidance_pair(rank: int, world: int):
+    """Optional single-clip latency mode: the two halves of a classifier-free-guidance batch (same
+    latents, unconditional / conditional context) run on the two GPUs of a pair and exchange their noise predictions every step
+    (0.5 MB per rank at 16x64x64) instead of running back to back on one GPU.  Ranks (2p, 2p+1) form pair p; returns
+    (pair index, role, process group) with role 0 = unconditional half, 1 = conditional half.  Every rank must call this (the
+    sub-groups are created collectively)."""
+    if world % 2:
+        raise ValueError("guidance-parallel mode needs an even number of ranks")
+    if world not in _pair_groups:
+        _pair_groups[world] = [dist.new_group([2 * p, 2 * p + 1]) for p in range(world // 2)]
+    return rank // 2, rank % 2, _pair_groups[world][rank // 2]
+
+
+def all_gather_cat(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate `t` of every rank of `group` along dim 0, in rank order (one all-gather: RCCL on the GPUs, gloo in the CPU tests)."""
+    n = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(t) for _ in range(n)]
+        dist.all_gather(parts, t.contiguous(), group=group)
+        return torch.cat(parts)
+    out = torch.empty((n * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out

@@ -195,7 +195,7 @@ def eval(pipeline, validation_data, out_file, index, forward_t=25, preview=True,
 
 def batch_eval(unet, text_encoder, vae, tokenizer, scheduler_config, validation_data, output_dir, preview,
                global_step=0, iters=6, generator=None, indices=None, seed=None, lora_path=None, lora_rank=16,
-               unet_lora_modules=("UNet3DConditionModel",)):
+               unet_lora_modules=("UNet3DConditionModel",), guidance_group=None):
     """train.py:793-823: pipeline with DPM-Solver++ built from the checkpoint's scheduler config, `iters` samples.
     `indices` (clip sharding, main_eval): render only these sample indices, each with its own generator seeded
     `seed + index` (distributed.clip_seed) so that a sample does not depend on which rank renders it."""
@@ -203,6 +203,7 @@ def batch_eval(unet, text_encoder, vae, tokenizer, scheduler_config, validation_
     scheduler = DPMSolverMultistepScheduler.from_config(scheduler_config)
     pipeline = LatentToVideoPipeline(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, unet=unet,
                                      scheduler=scheduler)
+    pipeline.guidance_group = guidance_group              # latency mode: the guidance halves of a clip on the two GPUs of a pair
     if lora_path:                                         # train_lora.py:909-917: adapters for inference (folded, not wrapped)
         from .lora import inject_inferable_lora
         inject_inferable_lora(pipeline, lora_path, r=lora_rank, unet_replace_modules=unet_lora_modules)
@@ -224,7 +225,7 @@ def batch_eval(unet, text_encoder, vae, tokenizer, scheduler_config, validation_
 
 def main_eval(pretrained_model_path, validation_data, seed=None, motion_mask=None, motion_strength=None,
               output_dir="output/demo", iters=6, dtype="fp16", graph=True, lora_path=None, lora_rank=16,
-              unet_lora_modules=("UNet3DConditionModel",), **kwargs):
+              unet_lora_modules=("UNet3DConditionModel",), guidance_parallel=False, **kwargs):
     """train.py:825-857.  Weights are cast to half precision on the GPU ("cuda" is the HIP device on ROCm).
     The reference accepts `motion_mask` / `motion_strength` here and never forwards them to the UNet constructor
     (train.py:838: the checkpoint's config.json governs); so do we - they are passed on only when the YAML sets them.
@@ -250,6 +251,14 @@ def main_eval(pretrained_model_path, validation_data, seed=None, motion_mask=Non
     if world == 1:
         return batch_eval(unet, text_encoder, vae, tokenizer, scfg, validation_data, output_dir, True, iters=iters,
                           generator=generator, lora_path=lora_path, lora_rank=lora_rank, unet_lora_modules=unet_lora_modules)
+    if guidance_parallel:
+        # latency mode (`guidance_parallel=true`): ranks (2p, 2p+1) share one clip - unconditional / text half of its guidance
+        # batch - and exchange the UNet outputs every step; the clips are sharded over the pairs; rank 2p writes the files
+        pair, role, group = D.guidance_pair(rank, world)
+        return batch_eval(unet, text_encoder, vae, tokenizer, scfg, validation_data, output_dir, role == 0, iters=iters,
+                          indices=D.clip_indices(iters, pair, world // 2), seed=seed if seed is not None else 0,
+                          lora_path=lora_path, lora_rank=lora_rank, unet_lora_modules=unet_lora_modules,
+                          guidance_group=(role, group))
     mine = D.clip_indices(iters, rank, world)
     results = batch_eval(unet, text_encoder, vae, tokenizer, scfg, validation_data, output_dir, True, iters=iters,
                          generator=generator, indices=mine, seed=seed, lora_path=lora_path, lora_rank=lora_rank,

@@ -89,3 +89,36 @@ def test_single_rank_is_identity():
     assert D.gather_clips(x, 3, 0, 1) is x
     assert D.clip_indices(5, 1, 2) == [1, 3]
     assert D.clip_seed(7, 3) == 10
+
+
+def _pair_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AA_EMU_THREADS="4")
+    torch.set_num_threads(2)
+    r, w, dev = D.init("gloo")
+    pair, role, group = D.guidance_pair(r, w)
+    from animate_anything_amd import _lib
+    lib, pipe = _pipeline()
+    pipe.guidance_group = (role, group)
+    with _lib.use_library(lib, host_pointers=True):
+        out = _denoise_clip(pipe, 0, 100)
+    q.put((rank, pair, role, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_guidance_parallel_pair_matches_one_rank():
+    """Latency mode: the unconditional and the text half of one clip's guidance batch on two ranks, one all-gather of the
+    UNet outputs per step (gloo here, RCCL on the GPUs) - same latents as the single-rank loop on both ranks."""
+    want = _run_clips([0], 100)[0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 137) % 500)
+    procs = [ctx.Process(target=_pair_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = [q.get(timeout=300) for _ in range(2)]
+    [p.join(60) for p in procs]
+    assert sorted((g[0], g[1], g[2]) for g in got) == [(0, 0, 0), (1, 0, 1)]
+    assert torch.equal(got[0][3], got[1][3])                       # both ranks hold the same latents
+    err = (got[0][3].float() - want.float()).abs().max() / want.float().abs().max()
+    assert err < 2e-3, err                                         # (batch 1 vs batch 2 contractions may pick other tile plans)
