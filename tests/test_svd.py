@@ -343,3 +343,16 @@ def test_encode_image_through_a_transformers_clip_vision_tower():
     assert torch.allclose(e[1, 0], want[0], atol=1e-6)
     ready = torch.randn(1, 1, 64)
     assert torch.equal(pipe._encode_image(img, torch.device("cpu"), 1, False, ready), ready)
+
+
+def test_parameter_counts_of_the_real_architectures():
+    """Structural known-answer test: with the default (stable-video-diffusion-img2vid) configuration the modules have
+    1 524 623 082 and 97 742 847 parameters - the sizes of the published fp16 checkpoints (3.05 GB UNet, 196 MB VAE = 2 bytes per
+    parameter) - and the reference's mask channel adds 320 x 3 x 3 input weights."""
+    with torch.device("meta"):
+        unet8 = UNetSpatioTemporalConditionModel()
+        unet9 = UNetSpatioTemporalConditionModel(in_channels=9)
+        vae = AutoencoderKLTemporalDecoder()
+    count = lambda m: sum(p.numel() for p in m.parameters())
+    assert count(unet8) == 1524623082 and count(unet9) - count(unet8) == 320 * 9
+    assert count(vae) == 97742847
