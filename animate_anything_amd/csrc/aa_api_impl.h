@@ -11,6 +11,7 @@
 #include "kernels/conv_gemm.h"
 #include "kernels/conv_gemm_dma.h"
 #include "kernels/conv_slab.h"
+#include "kernels/conv_gemm_x.h"
 #include "kernels/norm.h"
 #include "kernels/attention.h"
 #include "kernels/glue.h"
@@ -38,7 +39,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tile configurations of the LDS-DMA contraction kernel.  `rate` is the relative throughput of a tile
 // shape once the CUs are full (measured: the L2 -> LDS stream limits the narrow tiles); the chooser
 // minimises rounds(tiles / resident slots) * tile work / rate over the shapes that divide the packed width.
-struct CgCfg { int bm, bn, wm, wn, bk, stages, per_cu; float rate; int slab = 0; };   // slab: conv_slab.h (3x3 stride-1 halo-slab kernel)
+struct CgCfg { int bm, bn, wm, wn, bk, stages, per_cu; float rate; int slab = 0; int x = 0; };   // slab: conv_slab.h (3x3 stride-1 halo-slab kernel); x: conv_gemm_x.h
 static const CgCfg kCgCfgs[] = {
     {128, 64, 2, 2, 64, 2, 3, 0.78f},     // 0
     {128, 128, 2, 2, 64, 2, 2, 0.90f},    // 1
@@ -78,6 +79,13 @@ static const CgCfg kCgCfgs[] = {
     // halo-slab 3x3 kernel (conv_slab.h): the activations of a 32-channel unit are staged once for all nine taps
     {256, 320, 4, 2, 32, 3, 1, 1.00f, 1}, // 34
     {256, 256, 4, 2, 32, 3, 1, 1.00f, 1}, // 35
+    // hand-placed instruction stream, accumulators in a[0:255] (conv_gemm_x.h): one wave per SIMD, 128x128 / 128x160 per wave
+    {256, 256, 2, 2, 64, 2, 1, 1.45f, 0, 1}, // 36 DMA pieces of the tile after next under sub-steps 3 / 0 (8 + 8)
+    {256, 320, 2, 2, 64, 2, 1, 1.45f, 0, 1}, // 37 (11 + 7)
+    {256, 256, 2, 2, 64, 2, 1, 1.40f, 0, 1}, // 38 pieces spread over sub-steps 3 / 0 / 1 (6 + 5 + 5)
+    {256, 320, 2, 2, 64, 2, 1, 1.40f, 0, 1}, // 39 (7 + 6 + 5)
+    // the same stream with two waves per SIMD (64x128 per wave)
+    {256, 256, 4, 2, 64, 2, 1, 1.35f, 0, 1}, // 40
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -95,6 +103,9 @@ static bool cg_slab_ok(const AaConvGemm& d, const CgCfg& c) {
            c.bm % d.w_in == 0 && hw % c.bm == 0 && (c.bm / d.w_in + 2) * (d.w_in + 2) <= CS_SLAB_ROWS && !(d.debug & 8);
 }
 
+// The hand-scheduled tiles (conv_gemm_x.h) do not carry the nearest-neighbour resize of Upsample2D.
+static bool cg_x_ok(const AaConvGemm& d) { return d.h_virt == d.h_in && d.w_virt == d.w_in && !(d.debug & 8); }
+
 static int cg_choose(const AaConvGemm& d, int M) {
     int best = -1;
     double best_cost = 0.0;
@@ -104,6 +115,7 @@ static int cg_choose(const AaConvGemm& d, int M) {
         if (d.n_pad % c.bn) continue;
         if (d.geglu && (c.bn / c.wn) % 64) continue;          // value / gate blocks pair up inside one wavefront
         if (c.slab && !cg_slab_ok(d, c)) continue;
+        if (c.x && !cg_x_ok(d)) continue;
         if (forced == i) return i;
         const double tiles = (double)((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
         const double slots = 256.0 * c.per_cu;
@@ -205,6 +217,13 @@ static void cg_launch_slab(const AaConvGemm& d, int m_begin, int m_end, void* st
     AA_LAUNCH((conv3x3_slab_kernel<T, BM, BN, WM, WN>), grid, block, cs_lds_bytes(BN), stream, d, m_end, tiles_n, m_begin);
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int DP3, int DP0, int DP1>
+static void cg_launch_x(const AaConvGemm& d, int m_begin, int m_end, int splits, void* stream) {
+    const int tiles_n = d.n_pad / BN;
+    const dim3 grid(((m_end - m_begin + BM - 1) / BM) * tiles_n, splits), block(64 * WM * WN);
+    AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, DP3, DP0, DP1>), grid, block, cgx_lds_bytes(BM, BN), stream, d, m_end, tiles_n, m_begin, splits);
+}
+
 template <typename T>
 static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, void* stream, int splits = 1) {
     switch (cfg) {
@@ -244,6 +263,11 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 33: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2, false, true>(d, m_begin, m_end, splits, stream); break;
         case 34: cg_launch_slab<T, 256, 320, 4, 2>(d, m_begin, m_end, stream); break;
         case 35: cg_launch_slab<T, 256, 256, 4, 2>(d, m_begin, m_end, stream); break;
+        case 36: cg_launch_x<T, 256, 256, 2, 2, 8, 8, 0>(d, m_begin, m_end, splits, stream); break;
+        case 37: cg_launch_x<T, 256, 320, 2, 2, 11, 7, 0>(d, m_begin, m_end, splits, stream); break;
+        case 38: cg_launch_x<T, 256, 256, 2, 2, 6, 5, 5>(d, m_begin, m_end, splits, stream); break;
+        case 39: cg_launch_x<T, 256, 320, 2, 2, 7, 6, 5>(d, m_begin, m_end, splits, stream); break;
+        case 40: cg_launch_x<T, 256, 256, 4, 2, 2, 2, 2>(d, m_begin, m_end, splits, stream); break;
         default: return false;
     }
     return true;
@@ -349,6 +373,7 @@ int aa_conv_gemm_tile_ok(const AaConvGemm* d, int idx) {
     if (d->n_pad % c.bn) return 0;
     if (d->geglu && (c.bn / c.wn) % 64) return 0;
     if (c.slab && !cg_slab_ok(*d, c)) return 0;
+    if (c.x && !cg_x_ok(*d)) return 0;
     return 1;
 }
 void aa_set_tile_override(int cfg) { aa::g_tile_override = cfg < 0 ? -1 : cfg; }

@@ -36,9 +36,10 @@ __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages)
 // GEGLU (value block j, gate block j+1 sit in the same lane) and the residual are applied on the way out.
 //   m_wave  first output row of this wave's blocks          n_wave  first (packed) output column of this wave's blocks
 //   sBiasW  the bias slice of those columns in LDS
-template <typename T, int MI, int NI>
-__device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f32x16 (&acc)[MI][NI], const int m_wave, const int n_wave,
-                                             const T* sBiasW) {
+template <typename T, int MI, int NI, typename Get>
+__device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW) {
+    // get(IntTag<i>, IntTag<j>) -> the 16 accumulators of 32x32 block (i, j) of this lane (an array element, or a read-out
+    // of the literal accumulation registers of conv_gemm_x.h)
     const int lane = threadIdx.x & 63;
     const int ec = lane & 31, eh = lane >> 5;              // lane owns output row ec, columns 16*eh .. +15 of a block
     const T* rowvec = reinterpret_cast<const T*>(p.rowvec);
@@ -52,8 +53,8 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
     const bool pre_is_rv = rowvec != nullptr;             // the prefetch registers carry the row vector, else the residual
 #define AA_ZERO4 (u32x4{0u, 0u, 0u, 0u})          /* a prvalue: `c ? arr[i] : zero_variable` would select between ADDRESSES and pin arr in scratch */
     auto col_of = [&](int j) __attribute__((always_inline)) { return p.geglu ? (n_wave >> 1) + (j >> 1) * 32 + 16 * eh : n_wave + j * 32 + 16 * eh; };
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    static_for<MI>([&](auto i_) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_)::value;
         const int m = m_wave + i * 32 + ec;
         const bool m_ok = m < M;
         const int mc = m_ok ? m : M - 1;
@@ -88,7 +89,9 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
                 if (m_ok && nc + 8 * q + 8 <= n_cols) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o.raw;
             }
         };
-        auto block_f32 = [&](int j, float (&v)[2][8]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU) in fp32
+        auto block_f32 = [&](auto j_, float (&v)[2][8]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU) in fp32
+            constexpr int j = decltype(j_)::value;
+            const f32x16 a = get(IntTag<i>(), IntTag<j>());
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 Pack8<T> b; b.raw = *reinterpret_cast<const u32x4*>(sBiasW + (j * 32 + 16 * eh + 8 * q));
@@ -96,7 +99,7 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
                 Pack8<T> r; r.raw = AA_ZERO4;
                 if (pre_is_rv) r.raw = pv;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[q][e] = acc[i][j][8 * q + e] + (float)b.e[e] + brow;
+                for (int e = 0; e < 8; ++e) v[q][e] = a[8 * q + e] + (float)b.e[e] + brow;
                 if (pre_is_rv) {                          // uniform branches once per eight values, not once per value
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[q][e] += (float)r.e[e];
@@ -109,29 +112,35 @@ __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f
         };
         if (p.geglu) {
             if constexpr (NI % 2 == 0) {
-#pragma unroll
-                for (int j = 0; j < NI; j += 2) {
+                static_for<NI / 2>([&](auto h_) __attribute__((always_inline)) {
+                    constexpr int j = 2 * decltype(h_)::value;
                     // value * gelu(gate) in fp32 on the accumulators, ONE rounding to the storage type
                     float val[2][8], gate[2][8];
-                    block_f32(j, val);
-                    block_f32(j + 1, gate);
+                    block_f32(IntTag<j>(), val);
+                    block_f32(IntTag<j + 1>(), gate);
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) val[q][e] *= gelu_erf_f(gate[q][e]);
                     finish_block(j, val);
-                }
+                });
             }
         } else {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
+            static_for<NI>([&](auto j_) __attribute__((always_inline)) {
                 float v[2][8];
-                block_f32(j, v);
-                finish_block(j, v);
-            }
+                block_f32(j_, v);
+                finish_block(decltype(j_)::value, v);
+            });
         }
-    }
+    });
 #undef AA_ZERO4
+}
+
+template <typename T, int MI, int NI>
+__device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f32x16 (&acc)[MI][NI], const int m_wave, const int n_wave,
+                                             const T* sBiasW) {
+    cgd_epilogue_g<T, MI, NI>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) -> const f32x16& { return acc[decltype(i_)::value][decltype(j_)::value]; },
+                              m_wave, n_wave, sBiasW);
 }
 
 // PER_CU = workgroups meant to be co-resident on a CU (register budget: 512 / (PER_CU * waves per SIMD)).

@@ -1,0 +1,291 @@
+// Implicit-GEMM convolution / linear kernel with a HAND-PLACED instruction stream ("x" tiles of the tile table).
+//
+// Same operand path as conv_gemm_dma.h (buffer-descriptor LDS-DMA, source-side XOR swizzle, transposed
+// v_mfma_f32_32x32x16 whose accumulator registers are 16 consecutive output columns, register-direct epilogue),
+// but the K loop is not left to the compiler's scheduler:
+//  * the accumulators live in the accumulation half of the unified register file under LITERAL names
+//    (a[16 b : 16 b + 15] for 32x32 block b; blocks 16.. of the 320-column tile in compiler-allocated VGPRs):
+//    a 4-wave workgroup (one wave per SIMD, 512 registers per lane) owns a 256 x 256 or 256 x 320 tile with
+//    128 x 128 / 128 x 160 outputs per wave = 0.5 / 0.45 fragment reads per MFMA instead of 0.75 / 0.7, and the
+//    compiler's register allocator never sees them (no spills, no copies);
+//  * every MFMA, fragment read, DMA piece, wait and barrier is one `asm volatile` statement, so their program
+//    order IS the issue order: the gap behind each MFMA carries at most one fragment read of the next sub-step
+//    or one LDS-DMA piece of the tile after next (the CU's texture-address unit takes one 1-KiB piece per 16 clk:
+//    pieces issued in a burst hold every wave in its queue with the matrix pipe idle; one piece per 32-clk MFMA
+//    slot never queues);
+//  * the barrier of a K step sits BEFORE its last sub-step: once the fragments of sub-step 3 are in registers the
+//    stage is free, so the DMA of the tile after next and the first fragment reads of the next tile are issued
+//    under the 16 - 20 MFMAs of sub-step 3 and the matrix pipe does not drain at the step boundary.
+// Per K step and wave (256 x 256): 64 MFMA, 32 ds_read_b128, 16 DMA pieces, one barrier.
+#pragma once
+#include "dev.h"
+#include "aa_mi355.h"
+#include "conv_gemm_dma.h"
+
+namespace aa {
+
+__host__ __device__ inline int cgx_lds_bytes(int bm, int bn) { return cgd_lds_bytes(bm, bn, 64, 2); }
+
+// DP3 / DP0 / DP1: LDS-DMA pieces (per wave) of the tile after next issued under sub-step 3 of a K step and under
+// sub-steps 0 / 1 of the following one (the rest under sub-step 2); activations first (they may come from HBM).
+template <typename T, int BM, int BN, int WM, int WN, int DP3, int DP0, int DP1>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv_gemm_x_kernel(const AaConvGemm p, const int M, const int tiles_n, const int m_begin, const int k_splits) {
+    constexpr int BK = 64, STAGES = 2;
+    constexpr int NW = WM * WN;
+    constexpr int MI = BM / WM / 32;     // 32-row accumulator blocks per wave
+    constexpr int NI = BN / WN / 32;     // 32-column accumulator blocks per wave
+    constexpr int NB = MI * NI;          // accumulator blocks per wave: block i * NI + j
+    constexpr int ROWB = BK * 2;         // bytes per LDS tile row
+    constexpr int SPR = BK / 8;          // 16-byte slots per row
+    constexpr int RPI = 64 / SPR;        // tile rows deposited by one wave DMA instruction
+    constexpr int RPB = 256 / ROWB;      // tile rows per 256-byte LDS bank row
+    constexpr int GA = BM / RPI, GB = BN / RPI;
+    constexpr int AJ = (GA + NW - 1) / NW;
+    constexpr int BJ = (GB + NW - 1) / NW;
+    constexpr int PER_TILE = AJ + BJ;
+    constexpr int DP2 = PER_TILE - DP3 - DP0 - DP1;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int R = MI + NI;           // fragment reads per sub-step
+    constexpr int KS = BK / 16;
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % RPI == 0 && BN % RPI == 0, "tile shape");
+    static_assert(NB <= ACC_BLOCKS && R <= NB, "accumulator file");
+    static_assert(DP2 >= 0 && DP3 >= 0 && DP0 >= 0 && DP1 >= 0 && KS == 4, "DMA schedule");
+    static_assert(BN * 2 <= 1024, "bias slice");
+    char* smem = dyn_smem();
+    char* dummy = smem + STAGES * STAGE_BYTES;
+    T* sBias = reinterpret_cast<T*>(dummy + 1024);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_id();
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile_m = logical / tiles_n;
+    const int tile_n = logical - tile_m * tiles_n;
+
+    const int ctot = p.c0 + p.c1;
+    const int nk_all = p.k_pad / BK;
+    const int k_per = (nk_all + k_splits - 1) / k_splits;
+    const int kbase = blockIdx.y * k_per;
+    const int nk = max(0, min(k_per, nk_all - kbase));
+    // (convolutions behind a nearest-neighbour resize - Upsample2D - stay with conv_gemm_dma.h: aa_conv_gemm_tile_ok)
+    const bool linear = p.kh * p.kw == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0;
+
+    // ---- DMA geometry (as conv_gemm_dma.h): this lane feeds LDS rows ((wave + NW*j)*RPI + lane/SPR), 16-byte position lane%SPR
+    constexpr unsigned OOB = 0x80000000u;
+    const BufRsrc r_a0 = make_rsrc(p.a0, (unsigned)((int64_t)p.n_img * p.h_in * p.w_in * p.c0 * 2));
+    const BufRsrc r_a1 = make_rsrc(p.a1, p.c1 ? (unsigned)((int64_t)p.n_img * p.h_in * p.w_in * p.c1 * 2) : 0u);
+    const BufRsrc r_w = make_rsrc(p.w, (unsigned)((int64_t)p.n_pad * p.k_pad * 2));
+    constexpr int swm = SPR - 1;
+    const bool two_src = p.c1 != 0;
+    const int lrow = lane / SPR, lpos = lane % SPR;
+    // per fed activation row: its top-left tap pixel, and which taps read a real pixel (bits 0..7 rows dy, 8..15 columns dx;
+    // 0 for rows outside the tile).  The lane's swizzled 16-byte k-slot is the same for every piece (RPI * NW rows apart).
+    int pix[AJ];
+    unsigned vmask[AJ];
+    struct RowCoords { int img, iy, ix; bool ok; };
+    auto row_coords = [&](int j) __attribute__((always_inline)) {
+        const int rr = (wave + NW * j) * RPI + lrow;
+        const int m = m_begin + tile_m * BM + rr;
+        const bool ok = m < M && rr < BM;
+        const int mm = ok ? m : 0;
+        if (linear) return RowCoords{0, 0, mm, ok};
+        const int x = mm % p.w_out;
+        const int t = mm / p.w_out;
+        const int y = t % p.h_out;
+        return RowCoords{t / p.h_out, y * p.stride - p.pad_h, x * p.stride - p.pad_w, ok};
+    };
+    static_assert((RPI * NW / RPB) % SPR == 0, "the swizzle term must not depend on the piece index");
+    const unsigned slot16 = (unsigned)((lpos ^ (((wave * RPI + lrow) / RPB) & swm)) * 16);
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const RowCoords rc = row_coords(j);
+        const int iy = rc.iy, ix = rc.ix;
+        pix[j] = (rc.img * p.h_in + iy) * p.w_in + ix;                             // may be "negative": only used for in-range taps
+        const int ylo = max(0, -iy), yhi = max(ylo, min(p.kh, p.h_virt - iy));
+        const int xlo = max(0, -ix), xhi = max(xlo, min(p.kw, p.w_virt - ix));
+        const unsigned my = ((1u << yhi) - 1u) ^ ((1u << ylo) - 1u), mx = ((1u << xhi) - 1u) ^ ((1u << xlo) - 1u);
+        vmask[j] = rc.ok ? (my | (mx << 8)) : 0u;
+    }
+    // weight panel: this lane's row of piece 0; piece j is NW * RPI rows further (a wave-uniform offset)
+    const unsigned wb0 = (unsigned)((tile_n * BN + wave * RPI + lrow) * p.k_pad) * 2u + slot16;
+    const unsigned wb_step = (unsigned)(NW * RPI * p.k_pad) * 2u;
+    const int taps = p.kh * p.kw;
+
+    // K position of the next prepare() call (wave-uniform scalars, advanced incrementally; see conv_gemm_dma.h)
+    int n_tap, n_dy, n_dx, n_cb;
+    {
+        const int k0 = kbase * BK;
+        if (p.k_order) { const int unit = k0 >> 6; const int chunk = unit / taps; n_tap = unit - chunk * taps; n_cb = chunk * 64 + (k0 & 63); }
+        else           { n_tap = k0 / ctot; n_cb = k0 - n_tap * ctot; }
+        n_dy = n_tap / p.kw; n_dx = n_tap - n_dy * p.kw;
+    }
+    int cur_tap = -1, cur_src = -1;
+    unsigned pb[AJ];                     // byte offset of each fed row's source pixel for the current (tap, source) (OOB = halo / tail)
+    bool is_src1 = false;
+    unsigned is_ccb = 0u, is_kb = 0u;
+    int is_buf = 0;
+    auto prepare = [&](int kt, int buf) {
+        const int tap = n_tap, cb = n_cb, dy = n_dy, dx = n_dx;
+        {
+            const bool wrap_x = n_dx + 1 == p.kw;
+            if (p.k_order) {
+                const bool last_tap = n_tap + 1 == taps;
+                n_cb = (n_cb & ~63) + (last_tap ? 64 : 0);
+                const int t1 = last_tap ? 0 : n_tap + 1;
+                const int y1 = last_tap ? 0 : (wrap_x ? n_dy + 1 : n_dy);
+                const int x1 = (last_tap || wrap_x) ? 0 : n_dx + 1;
+                n_tap = t1; n_dy = y1; n_dx = x1;
+            } else {
+                const bool last_c = n_cb + BK >= ctot;
+                n_cb = last_c ? 0 : n_cb + BK;
+                n_tap = last_c ? n_tap + 1 : n_tap;
+                n_dy = (last_c && wrap_x) ? n_dy + 1 : n_dy;
+                n_dx = last_c ? (wrap_x ? 0 : n_dx + 1) : n_dx;
+            }
+        }
+        is_src1 = cb >= p.c0;
+        const int src = is_src1 ? 1 : 0;
+        if (tap != cur_tap || src != cur_src) {
+            cur_tap = tap; cur_src = src;
+            const bool tap_ok = tap < taps;
+            const int csrc = is_src1 ? p.c1 : p.c0;
+            const int d = dy * p.w_in + dx;
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const bool ok = tap_ok && (((vmask[j] >> dy) & (vmask[j] >> (8 + dx))) & 1u);
+                pb[j] = ok ? (unsigned)((pix[j] + d) * csrc) * 2u + slot16 : OOB;
+            }
+        }
+        is_ccb = (unsigned)(is_src1 ? cb - p.c0 : cb) * 2u;
+        is_kb = (unsigned)((kbase + kt) * BK) * 2u;
+        is_buf = buf;
+    };
+    // DMA piece JJ of the prepared tile: pieces < AJ feed activation rows, the rest weight rows.  The wave-uniform parts
+    // of the source address (channel chunk; K position and piece row of the weights) travel in the scalar offset.
+    auto dma_piece = [&](auto jj_) __attribute__((always_inline)) {
+        constexpr int jj = decltype(jj_)::value;
+        if constexpr (jj < AJ) {
+            constexpr int j = jj;
+            const bool real = (GA % NW == 0) || (wave + NW * j < GA);
+            char* a = smem + is_buf * STAGE_BYTES + wave * RPI * ROWB;
+            async_copy16_buf_s(is_src1 ? r_a1 : r_a0, real ? pb[j] : OOB, is_ccb, real ? a + j * NW * RPI * ROWB : dummy);
+        } else {
+            constexpr int j = jj - AJ;
+            const bool real = (GB % NW == 0) || (wave + NW * j < GB);
+            char* b = smem + is_buf * STAGE_BYTES + BM * ROWB + wave * RPI * ROWB;
+            async_copy16_buf_s(r_w, real ? wb0 : OOB, is_kb + j * wb_step, real ? b + j * NW * RPI * ROWB : dummy);
+        }
+    };
+    auto dma_range = [&](auto j0_, auto j1_) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(j0_)::value, J1 = decltype(j1_)::value;
+        static_for<J1 - J0>([&](auto t) __attribute__((always_inline)) { dma_piece(IntTag<J0 + decltype(t)::value>()); });
+    };
+
+    // ---- fragment read addresses: row = base + (lane&31), k-slot ks*2 + (lane>>5), un-swizzled per row.  A row is 128 bytes
+    // and every stage starts on a multiple of 128, so the byte address of sub-step ks is (address of sub-step 0) ^ (ks << 5):
+    // one register per fragment row block, the sub-step is an XOR constant inside the read statement
+    const int frow = lane & 31, fh = lane >> 5;
+    int a_off[MI], w_off[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { const int rr = wm * (BM / WM) + i * 32 + frow; a_off[i] = rr * ROWB + ((fh ^ ((rr / RPB) & swm)) << 4); }
+    const int prow = (frow & 3) + 4 * (frow >> 3) + 16 * ((frow >> 2) & 1);          // permuted weight rows: conv_gemm_dma.h
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + prow; w_off[j] = BM * ROWB + rr * ROWB + ((fh ^ ((rr / RPB) & swm)) << 4); }
+    static_assert(ROWB == 128 && STAGE_BYTES % 128 == 0 && RPB == 2 && swm == 7, "XOR addressing of the k sub-steps");
+
+    AccFile af;
+    static_for<NB>([&](auto b) __attribute__((always_inline)) { acc_zero<decltype(b)::value>(af); });
+
+    u32x4 fa[2][MI], fw[2][NI];
+    // read number rd of sub-step ks of the stage at `st` into fragment set `set` (order of first use: a0, w0 .. w(NI-1), a1 ..)
+    auto frag_read = [&](const char* st, auto ks_, auto set_, auto rd_) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_)::value, set = decltype(set_)::value, rd = decltype(rd_)::value;
+        if constexpr (rd == 0)       lds_read16_xor(fa[set][0], st + a_off[0], IntTag<(ks << 5)>());
+        else if constexpr (rd <= NI) lds_read16_xor(fw[set][rd - 1], st + w_off[rd - 1], IntTag<(ks << 5)>());
+        else                         lds_read16_xor(fa[set][rd - NI], st + a_off[rd - NI], IntTag<(ks << 5)>());
+    };
+    // One sub-step: NB MFMAs out of fragment set ks&1; the gap behind MFMA g carries read g of the NEXT sub-step (g < R,
+    // from stage `st_rd`, sub-step KSN) and / or DMA piece (DJ0 + g - G0) of the prepared tile for g in [G0, G0 + DN).
+    auto substep = [&](auto ks_, auto ksn_, const char* st_rd, const bool do_read, auto dj0_, auto dn_) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_)::value, ksn = decltype(ksn_)::value, set = ks & 1;
+        constexpr int DJ0 = decltype(dj0_)::value, DN = decltype(dn_)::value;
+        constexpr int G0 = (DN <= NB - R) ? R : NB - DN;              // DMA pieces prefer the read-free gaps at the end
+        static_for<NB>([&](auto g_) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_)::value, i = g / NI, j = g % NI;
+            acc_mfma<i * NI + j>(af, T(), fw[set][j], fa[set][i]);
+            if constexpr (g < R) { if (do_read) frag_read(st_rd, IntTag<ksn>(), IntTag<set ^ 1>(), IntTag<g>()); }
+            if constexpr (DN > 0 && g >= G0 && g < G0 + DN) dma_piece(IntTag<DJ0 + g - G0>());
+        });
+        lds_wait_all();
+    };
+    // K step kt: HAS_NEXT = tile kt+1 exists (the rest of its DMA goes out under sub-steps 0..2, its first fragments are read
+    // under sub-step 3), HAS_NEXT2 = tile kt+2 exists (its first DP3 pieces go out under sub-step 3)
+    auto kstep = [&](int kt, auto has_next_, auto has_next2_) __attribute__((always_inline)) {
+        constexpr bool HAS_NEXT = decltype(has_next_)::value, HAS_NEXT2 = decltype(has_next2_)::value;
+        const char* st = smem + (kt & 1) * STAGE_BYTES;
+        const char* st_next = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        substep(IntTag<0>(), IntTag<1>(), st, true, IntTag<DP3>(), IntTag<HAS_NEXT ? DP0 : 0>());
+        substep(IntTag<1>(), IntTag<2>(), st, true, IntTag<DP3 + DP0>(), IntTag<HAS_NEXT ? DP1 : 0>());
+        substep(IntTag<2>(), IntTag<3>(), st, true, IntTag<DP3 + DP0 + DP1>(), IntTag<HAS_NEXT ? DP2 : 0>());
+        if constexpr (HAS_NEXT) {
+            dma_wait<0>();                                       // my pieces of tile kt+1 landed ...
+            block_barrier();                                     // ... everyone's did, and every wave holds its last fragments of tile kt
+        }
+        if constexpr (HAS_NEXT2) prepare(kt + 2, kt & 1);        // stage kt&1 is free from here on
+        substep(IntTag<3>(), IntTag<0>(), st_next, HAS_NEXT, IntTag<0>(), IntTag<HAS_NEXT2 ? DP3 : 0>());
+    };
+
+    if (nk > 0) {
+        prepare(0, 0);
+        dma_range(IntTag<0>(), IntTag<PER_TILE>());
+        if (nk > 1) { prepare(1, 1); dma_range(IntTag<0>(), IntTag<DP3>()); }
+        if (tid < BN / 8) {
+            const int n = tile_n * BN + tid * 8;
+            u32x4 b = u32x4{0u, 0u, 0u, 0u};
+            if (p.bias && !p.bias_per_row && n + 8 <= p.n_out) b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
+            *reinterpret_cast<u32x4*>(sBias + tid * 8) = b;
+        }
+        if (nk > 1) dma_wait<DP3>(); else dma_wait<0>();
+        block_barrier();
+        static_for<R>([&](auto rd) __attribute__((always_inline)) { frag_read(smem, IntTag<0>(), IntTag<0>(), rd); });
+        lds_wait_all();
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) kstep(kt, BoolTag<true>(), BoolTag<true>());
+        if (nk >= 2) { kstep(kt, BoolTag<true>(), BoolTag<false>()); ++kt; }
+        kstep(kt, BoolTag<false>(), BoolTag<false>());
+    } else {
+        if (tid < BN / 8) *reinterpret_cast<u32x4*>(sBias + tid * 8) = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+    acc_settle();                                                // MFMA results visible to v_accvgpr_read
+
+    const int ec = lane & 31, eh = lane >> 5;
+    const int m_tile = m_begin + tile_m * BM;
+    const int n_wave = tile_n * BN + wn * (BN / WN);
+    if (k_splits > 1) {
+        float* ws = reinterpret_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * (M - m_begin) - m_begin) * p.n_pad;
+        static_for<MI>([&](auto i_) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_)::value;
+            const int m = m_tile + wm * (BM / WM) + i * 32 + ec;
+            static_for<NI>([&](auto j_) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_)::value;
+                const f32x16 a = acc_get<i * NI + j>(af);
+                if (m < M) {
+                    float* dst = ws + (int64_t)m * p.n_pad + n_wave + j * 32 + 16 * eh;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(dst + 4 * qq) = f32x4{a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]};
+                }
+            });
+        });
+        return;
+    }
+    cgd_epilogue_g<T, MI, NI>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) { return acc_get<decltype(i_)::value * NI + decltype(j_)::value>(af); },
+                              m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN));
+}
+
+}  // namespace aa

@@ -85,3 +85,98 @@ template <int N>
 __device__ __forceinline__ void lds_wait(u32x4& x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N)); }
 // Order the consumers of `x` behind the preceding lds_wait (no instruction emitted).
 __device__ __forceinline__ void lds_pin(u32x4& x) { asm volatile("" : "+v"(x)); }
+
+// ---- accumulator file of the hand-scheduled contraction kernel (conv_gemm_x.h) --------------------------------------
+// 32x32 accumulator block b (16 fp32 per lane) lives under a LITERAL name in the accumulation half of the unified register
+// file, a[16 b : 16 b + 15], for b < 16 (a one-wave-per-SIMD kernel then has all 256 architectural VGPRs for fragments, DMA
+// offsets and the epilogue); blocks 16..19 (the 256 x 320 tile) sit in compiler-allocated VGPRs.  The MFMAs are
+// `asm volatile` statements: program order = issue order.  hipcc does not allocate the literal registers: every statement
+// that writes a block lists its 16 registers as clobbers, so hipcc (a) counts them in the kernel descriptor and (b) knows
+// nothing of its own survives there (without the clobbers it spills INTO accumulation registers it believes free as soon
+// as it runs short of VGPRs - seen in the first build of the 320-column tile).  Letting hipcc allocate the blocks through
+// "+a" operands was tried as well: it then shuffles accumulators between the two halves of the file around the loop
+// tails (864 v_accvgpr moves + 284 scratch accesses in one K step).  tests/test_abi.py audits the disassembly of these
+// kernels: no scratch, no compiler-made v_accvgpr_* (cdna guide 5.7 item 4).
+constexpr int ACC_BLOCKS = 20;
+struct AccFile { f32x16 v[ACC_BLOCKS - 16]; };
+#define AA_ACC_LITERAL_BLOCKS(X) \
+    X(0, "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15") \
+    X(1, "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31") \
+    X(2, "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47") \
+    X(3, "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63") \
+    X(4, "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79") \
+    X(5, "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95") \
+    X(6, "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111") \
+    X(7, "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127") \
+    X(8, "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143") \
+    X(9, "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159") \
+    X(10, "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175") \
+    X(11, "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191") \
+    X(12, "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207") \
+    X(13, "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223") \
+    X(14, "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239") \
+    X(15, "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255")
+template <int B>
+__device__ __forceinline__ void acc_zero(AccFile& af) {
+    if constexpr (B < 16) {
+#define AA_X(b, ...) if constexpr (B == b) asm volatile( \
+            "v_accvgpr_write_b32 a[%c0+0], 0\n\tv_accvgpr_write_b32 a[%c0+1], 0\n\tv_accvgpr_write_b32 a[%c0+2], 0\n\tv_accvgpr_write_b32 a[%c0+3], 0\n\t" \
+            "v_accvgpr_write_b32 a[%c0+4], 0\n\tv_accvgpr_write_b32 a[%c0+5], 0\n\tv_accvgpr_write_b32 a[%c0+6], 0\n\tv_accvgpr_write_b32 a[%c0+7], 0\n\t" \
+            "v_accvgpr_write_b32 a[%c0+8], 0\n\tv_accvgpr_write_b32 a[%c0+9], 0\n\tv_accvgpr_write_b32 a[%c0+10], 0\n\tv_accvgpr_write_b32 a[%c0+11], 0\n\t" \
+            "v_accvgpr_write_b32 a[%c0+12], 0\n\tv_accvgpr_write_b32 a[%c0+13], 0\n\tv_accvgpr_write_b32 a[%c0+14], 0\n\tv_accvgpr_write_b32 a[%c0+15], 0\n\t" \
+            "s_nop 4" ::"i"(16 * b) : __VA_ARGS__);
+        AA_ACC_LITERAL_BLOCKS(AA_X)
+#undef AA_X
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) af.v[B - 16][e] = 0.0f;
+        asm volatile("s_nop 4" : "+v"(af.v[B - 16]));
+    }
+}
+// block B += W(32 x 16, MFMA "A" operand: rows -> accumulator registers) * A(16 x 32, "B" operand: columns -> lanes)
+template <int B>
+__device__ __forceinline__ void acc_mfma(AccFile& af, f16_t, const u32x4& w, const u32x4& a) {
+    if constexpr (B < 16) {
+#define AA_X(b, ...) if constexpr (B == b) asm volatile("v_mfma_f32_32x32x16_f16 a[%c0:%c1], %2, %3, a[%c0:%c1]" ::"i"(16 * b), "i"(16 * b + 15), "v"(w), "v"(a) : __VA_ARGS__);
+        AA_ACC_LITERAL_BLOCKS(AA_X)
+#undef AA_X
+    } else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(af.v[B - 16]) : "v"(w), "v"(a));
+}
+template <int B>
+__device__ __forceinline__ void acc_mfma(AccFile& af, bf16_t, const u32x4& w, const u32x4& a) {
+    if constexpr (B < 16) {
+#define AA_X(b, ...) if constexpr (B == b) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], %2, %3, a[%c0:%c1]" ::"i"(16 * b), "i"(16 * b + 15), "v"(w), "v"(a) : __VA_ARGS__);
+        AA_ACC_LITERAL_BLOCKS(AA_X)
+#undef AA_X
+    } else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(af.v[B - 16]) : "v"(w), "v"(a));
+}
+// all MFMAs issued so far have written their accumulators (8-pass XDL -> VALU read needs 11 wait states; hipcc does not
+// know the statements above are MFMAs, so the states are spent by hand: 32)
+__device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+template <int B>
+__device__ __forceinline__ f32x16 acc_get(AccFile& af) {
+    if constexpr (B < 16) {
+        f32x16 r;
+#define AA_ACC_RD(e) asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(r[e]) : "i"(16 * B + e));
+        AA_ACC_RD(0) AA_ACC_RD(1) AA_ACC_RD(2) AA_ACC_RD(3) AA_ACC_RD(4) AA_ACC_RD(5) AA_ACC_RD(6) AA_ACC_RD(7)
+        AA_ACC_RD(8) AA_ACC_RD(9) AA_ACC_RD(10) AA_ACC_RD(11) AA_ACC_RD(12) AA_ACC_RD(13) AA_ACC_RD(14) AA_ACC_RD(15)
+#undef AA_ACC_RD
+        return r;
+    } else {
+        return af.v[B - 16];
+    }
+}
+// hand-issued 16-byte LDS read from (address ^ X): the XOR sits inside the statement (hipcc would otherwise keep one
+// precomputed address register per sub-step and fragment)
+template <int X>
+__device__ __forceinline__ void lds_read16_xor(u32x4& dst, const void* lds_ptr, IntTag<X>) {
+    const unsigned addr = (unsigned)(unsigned long long)lds_ptr;
+    if constexpr (X == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+    else { unsigned t; asm volatile("v_xor_b32 %1, %3, %2\n\tds_read_b128 %0, %1" : "=v"(dst), "=&v"(t) : "v"(addr), "i"(X)); }
+}
+// every hand-issued fragment read has landed
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// LDS-DMA piece with a wave-uniform byte offset on top of the per-lane one (the range check covers the per-lane part only)
+__device__ __forceinline__ void async_copy16_buf_s(const BufRsrc& r, unsigned lane_offset, unsigned uniform_offset, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.v, (__attribute__((address_space(3))) void*)lds_wave_base, 16, lane_offset, uniform_offset, 0, 0);
+}

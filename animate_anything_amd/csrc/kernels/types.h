@@ -23,3 +23,15 @@ union Pack8 {
 // compile-time integer carried as a type (lets a generic lambda take a constant)
 template <int N>
 struct IntTag { static constexpr int value = N; };
+template <bool B>
+struct BoolTag { static constexpr bool value = B; };
+// f(IntTag<0>()), f(IntTag<1>()), ... f(IntTag<N-1>()): a loop whose index is a constant expression inside the body
+#if defined(__HIPCC__)
+#define AA_HD __host__ __device__
+#else
+#define AA_HD
+#endif
+template <int N, int I = 0, typename F>
+AA_HD inline __attribute__((always_inline)) void static_for(F&& f) {
+    if constexpr (I < N) { f(IntTag<I>()); static_for<N, I + 1>(f); }
+}

@@ -255,3 +255,25 @@ inline void lds_pin(u32x4&) {}
 
 using std::fabs;
 inline float fabsf_(float x) { return std::fabs(x); }
+
+// accumulator file of conv_gemm_x.h: plain storage here
+constexpr int ACC_BLOCKS = 20;
+struct AccFile { f32x16 blk[ACC_BLOCKS]; };
+template <int B> inline void acc_zero(AccFile& af) { for (int e = 0; e < 16; ++e) af.blk[B][e] = 0.0f; }
+template <int B> inline void acc_mfma(AccFile& af, f16_t, const u32x4& w, const u32x4& a) { af.blk[B] = emu_mfma_32x32x16<f16_t>(w, a, af.blk[B]); }
+template <int B> inline void acc_mfma(AccFile& af, bf16_t, const u32x4& w, const u32x4& a) { af.blk[B] = emu_mfma_32x32x16<bf16_t>(w, a, af.blk[B]); }
+inline void acc_settle() {}
+template <int B> inline f32x16 acc_get(AccFile& af) { return af.blk[B]; }
+inline void lds_wait_all() {}
+template <int X>
+inline void lds_read16_xor(u32x4& dst, const void* lds_ptr, IntTag<X>) {
+    // (address ^ X) relative to the LDS base: the emulator's LDS buffer is 16-byte aligned only, so XOR the offset
+    char* base = dyn_smem();
+    const uintptr_t off = (uintptr_t)(static_cast<const char*>(lds_ptr) - base);
+    dst = *reinterpret_cast<const u32x4*>(base + (off ^ (uintptr_t)X));
+}
+inline void async_copy16_buf_s(const BufRsrc& r, unsigned lane_offset, unsigned uniform_offset, void* lds_wave_base) {
+    char* dst = static_cast<char*>(lds_wave_base) + (emu::linear_tid() & 63) * 16;
+    if ((unsigned long long)lane_offset + 16 <= r.bytes) std::memcpy(dst, r.base + uniform_offset + lane_offset, 16);
+    else std::memset(dst, 0, 16);
+}

@@ -313,7 +313,7 @@ def test_geglu_dma_path_wide(backend):
     close(y, (h[:, :D] * F.gelu(h[:, D:])).half().float() + r.float())
 
 
-@pytest.mark.parametrize("cfg,N", [(0, 320), (1, 640), (2, 256), (3, 256), (4, 640), (5, 320), (6, 320), (7, 512), (8, 128), (9, 64), (10, 640), (11, 320), (12, 256), (13, 512), (14, 320), (15, 256), (16, 128), (17, 64), (18, 128), (19, 64), (20, 256), (21, 320), (22, 256), (23, 256), (24, 256), (25, 256), (26, 320), (27, 256), (28, 256), (29, 640), (30, 320), (31, 128), (32, 320), (33, 256)])
+@pytest.mark.parametrize("cfg,N", [(0, 320), (1, 640), (2, 256), (3, 256), (4, 640), (5, 320), (6, 320), (7, 512), (8, 128), (9, 64), (10, 640), (11, 320), (12, 256), (13, 512), (14, 320), (15, 256), (16, 128), (17, 64), (18, 128), (19, 64), (20, 256), (21, 320), (22, 256), (23, 256), (24, 256), (25, 256), (26, 320), (27, 256), (28, 256), (29, 640), (30, 320), (31, 128), (32, 320), (33, 256), (36, 256), (37, 640), (38, 512), (39, 320), (40, 256)])
 def test_dma_tile_shapes(backend, cfg, N):
     """Every tile shape of the LDS-DMA kernel (forced), conv3x3 with halo + M tail + residual."""
     from animate_anything_amd import _lib
@@ -341,7 +341,7 @@ def test_geglu_wide_tiles(backend, D):
     close(ops.conv_gemm(x, pw, ops.linear_geom(M)), h[:, :D] * F.gelu(h[:, D:]))
 
 
-@pytest.mark.parametrize("cfg,splits", [(1, 3), (3, 5), (16, 2)])
+@pytest.mark.parametrize("cfg,splits", [(1, 3), (3, 5), (16, 2), (36, 5), (39, 3), (40, 2)])
 def test_explicit_k_splits(backend, cfg, splits):
     """Caller-chosen K split count (autotuner): uneven K ranges, fp32 partials, reduce launch with the fused epilogue."""
     from animate_anything_amd import _lib
@@ -361,7 +361,7 @@ def test_explicit_k_splits(backend, cfg, splits):
     close(y, ref)
 
 
-@pytest.mark.parametrize("cfg", [23, 25, 3])
+@pytest.mark.parametrize("cfg", [23, 25, 3, 36, 38, 40])
 def test_geglu_forced_tiles(backend, cfg):
     """GEGLU value/gate pairing inside one wavefront for the 4-wave-column tiles (NI = 2) and the 2-column ones (NI = 4)."""
     from animate_anything_amd import _lib
@@ -559,3 +559,62 @@ def test_halo_slab_eligibility(emu):
     assert lib.aa_conv_gemm_tile_ok(C.byref(d), 34) == 0
     d.stride, d.h_in, d.w_in, d.h_virt, d.w_virt, d.h_out, d.w_out = 1, 55, 74, 55, 74, 55, 74                  # irregular eval size
     assert lib.aa_conv_gemm_tile_ok(C.byref(d), 34) == 0 and lib.aa_conv_gemm_tile_ok(C.byref(d), 14) == 1
+
+
+X_TILES = [(36, 256), (37, 320), (38, 256), (39, 320), (40, 256)]
+
+
+@pytest.mark.parametrize("cfg,N", X_TILES)
+@pytest.mark.parametrize("K", [64, 128, 192, 320])
+def test_x_tiles_linear_every_loop_shape(backend, cfg, N, K):
+    """Hand-scheduled tiles (conv_gemm_x.h): K loops of 1, 2, 3 and 5 steps walk the prologue, the peeled first / last
+    K steps and the steady-state body; M tail, bias, SiLU, residual, scale."""
+    from animate_anything_amd import _lib
+    M = 300
+    x, w, b, r = rnd(M, K, seed=201), rnd(N, K, scale=0.1, seed=202), rnd(N, seed=203), rnd(M, N, seed=204)
+    lib = _lib.get()
+    lib.aa_set_tile_override(cfg)
+    try:
+        y = ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M), residual=r, act=ops.AA_ACT_SILU, out_scale=0.5)
+    finally:
+        lib.aa_set_tile_override(-1)
+    close(y, (F.silu(x.float() @ w.float().t() + b.float()) + r.float()) * 0.5)
+
+
+@pytest.mark.parametrize("cfg,N", X_TILES)
+def test_x_tiles_temporal_conv_and_two_sources(backend, cfg, N):
+    """(3,1,1) temporal convolution (taps = row shifts of H*W, clip borders masked) and a 3x3 convolution over the channel
+    concat of two tensors (up-block resnets) on the hand-scheduled tiles."""
+    from animate_anything_amd import _lib
+    lib = _lib.get()
+    clips, frames, hw, c = 2, 5, 30, N
+    x5 = rnd(clips, c, frames, hw, 1, seed=211)
+    wt, b = rnd(c, c, 3, 1, 1, scale=0.05, seed=212), rnd(c, seed=213)
+    tok = x5.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous()
+    n, h, w_, c0, c1 = 2, 9, 13, 64, 128
+    xa, xb = rnd(n, c0, h, w_, seed=214), rnd(n, c1, h, w_, seed=215)
+    w2, b2 = rnd(N, c0 + c1, 3, 3, scale=0.05, seed=216), rnd(N, seed=217)
+    lib.aa_set_tile_override(cfg)
+    try:
+        y = ops.conv_gemm(tok, ops.pack_weight(wt, b), ops.tconv_geom(clips, frames, hw), residual=tok)
+        y2 = ops.conv_gemm(nhwc(xa), ops.pack_weight(w2, b2), ops.conv3x3_geom(n, h, w_), x1=nhwc(xb))
+    finally:
+        lib.aa_set_tile_override(-1)
+    ref = F.conv3d(x5.float(), wt.float(), b.float(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, c) + tok.float()
+    close(y, ref)
+    close(y2, nhwc(F.conv2d(torch.cat([xa, xb], 1).float(), w2.float(), b2.float(), padding=1)))
+
+
+def test_x_tiles_are_not_offered_behind_a_resize(emu):
+    """aa_conv_gemm_tile_ok: the hand-scheduled tiles leave Upsample2D's nearest-neighbour resize to the compiled kernel."""
+    import ctypes as C
+    from animate_anything_amd import _lib
+    from animate_anything_amd._lib import AaConvGemm
+    lib = _lib.get()
+    d = AaConvGemm()
+    d.c0, d.c1, d.n_img, d.h_in, d.w_in, d.h_virt, d.w_virt, d.h_out, d.w_out = 640, 0, 34, 32, 32, 32, 32, 32, 32
+    d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.n_out, d.n_pad, d.k_pad, d.k_order = 3, 3, 1, 1, 1, 640, 640, 5760, 1
+    d.ldo, d.dtype, d.out_dtype = 640, 0, 0
+    assert lib.aa_conv_gemm_tile_ok(C.byref(d), 37) == 1 and lib.aa_conv_gemm_tile_ok(C.byref(d), 36) == 0   # 640 % 256
+    d.h_virt, d.w_virt, d.h_out, d.w_out = 64, 64, 64, 64
+    assert lib.aa_conv_gemm_tile_ok(C.byref(d), 37) == 0 and lib.aa_conv_gemm_tile_ok(C.byref(d), 14) == 1
