@@ -18,10 +18,13 @@ def _deps():
 PROBE_LIB = os.path.join(PKG, "libaa_mi355_probe.so")
 
 
-def build(force=False, verbose=False, probe=False):
+def build(force=False, verbose=False, probe=False, ablate=0):
     """Compile csrc/aa_api.hip -> libaa_mi355.so (skipped when up to date). Returns the path.
-    probe=True builds the -DAA_PHASE_PROBE profiling variant (scripts/phase_probe.py) next to it."""
+    probe=True builds the -DAA_PHASE_PROBE profiling variant (scripts/phase_probe.py) next to it;
+    ablate=bits a timing-only -DAA_X_ABLATE variant of the hand-scheduled kernels (scripts/x_ablate.py)."""
     LIB = PROBE_LIB if probe else globals()["LIB"]
+    if ablate:
+        LIB = os.path.join(PKG, f"libaa_mi355_abl{ablate}.so")
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _deps()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -31,6 +34,8 @@ def build(force=False, verbose=False, probe=False):
            os.path.join(CSRC, "aa_api.hip"), "-o", LIB]
     if probe:
         cmd.insert(1, "-DAA_PHASE_PROBE")
+    if ablate:
+        cmd.insert(1, f"-DAA_X_ABLATE={int(ablate)}")
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

@@ -86,6 +86,10 @@ static const CgCfg kCgCfgs[] = {
     {256, 320, 2, 2, 64, 2, 1, 1.40f, 0, 1}, // 39 (7 + 6 + 5)
     // the same stream with two waves per SIMD (64x128 per wave)
     {256, 256, 4, 2, 64, 2, 1, 1.35f, 0, 1}, // 40
+    // deep ring: four stages of 32 K, three of them in flight, counted waits (conv_gemm_x.h "BK = 32")
+    {256, 256, 2, 2, 32, 4, 1, 1.50f, 0, 1}, // 41 one wave per SIMD
+    {256, 320, 2, 2, 32, 4, 1, 1.50f, 0, 1}, // 42
+    {256, 256, 4, 2, 32, 4, 1, 1.45f, 0, 1}, // 43 two waves per SIMD
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -217,11 +221,11 @@ static void cg_launch_slab(const AaConvGemm& d, int m_begin, int m_end, void* st
     AA_LAUNCH((conv3x3_slab_kernel<T, BM, BN, WM, WN>), grid, block, cs_lds_bytes(BN), stream, d, m_end, tiles_n, m_begin);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int DP3, int DP0, int DP1>
+template <typename T, int BM, int BN, int WM, int WN, int BK, int DP3, int DP0, int DP1>
 static void cg_launch_x(const AaConvGemm& d, int m_begin, int m_end, int splits, void* stream) {
     const int tiles_n = d.n_pad / BN;
     const dim3 grid(((m_end - m_begin + BM - 1) / BM) * tiles_n, splits), block(64 * WM * WN);
-    AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, DP3, DP0, DP1>), grid, block, cgx_lds_bytes(BM, BN), stream, d, m_end, tiles_n, m_begin, splits);
+    AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1>), grid, block, cgx_lds_bytes(BM, BN), stream, d, m_end, tiles_n, m_begin, splits);
 }
 
 template <typename T>
@@ -263,11 +267,14 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 33: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2, false, true>(d, m_begin, m_end, splits, stream); break;
         case 34: cg_launch_slab<T, 256, 320, 4, 2>(d, m_begin, m_end, stream); break;
         case 35: cg_launch_slab<T, 256, 256, 4, 2>(d, m_begin, m_end, stream); break;
-        case 36: cg_launch_x<T, 256, 256, 2, 2, 8, 8, 0>(d, m_begin, m_end, splits, stream); break;
-        case 37: cg_launch_x<T, 256, 320, 2, 2, 11, 7, 0>(d, m_begin, m_end, splits, stream); break;
-        case 38: cg_launch_x<T, 256, 256, 2, 2, 6, 5, 5>(d, m_begin, m_end, splits, stream); break;
-        case 39: cg_launch_x<T, 256, 320, 2, 2, 7, 6, 5>(d, m_begin, m_end, splits, stream); break;
-        case 40: cg_launch_x<T, 256, 256, 4, 2, 2, 2, 2>(d, m_begin, m_end, splits, stream); break;
+        case 36: cg_launch_x<T, 256, 256, 2, 2, 64, 8, 8, 0>(d, m_begin, m_end, splits, stream); break;
+        case 37: cg_launch_x<T, 256, 320, 2, 2, 64, 11, 7, 0>(d, m_begin, m_end, splits, stream); break;
+        case 38: cg_launch_x<T, 256, 256, 2, 2, 64, 6, 5, 5>(d, m_begin, m_end, splits, stream); break;
+        case 39: cg_launch_x<T, 256, 320, 2, 2, 64, 7, 6, 5>(d, m_begin, m_end, splits, stream); break;
+        case 40: cg_launch_x<T, 256, 256, 4, 2, 64, 2, 2, 2>(d, m_begin, m_end, splits, stream); break;
+        case 41: cg_launch_x<T, 256, 256, 2, 2, 32, 4, 0, 0>(d, m_begin, m_end, splits, stream); break;
+        case 42: cg_launch_x<T, 256, 320, 2, 2, 32, 5, 0, 0>(d, m_begin, m_end, splits, stream); break;
+        case 43: cg_launch_x<T, 256, 256, 4, 2, 32, 2, 0, 0>(d, m_begin, m_end, splits, stream); break;
         default: return false;
     }
     return true;

@@ -24,13 +24,21 @@
 
 namespace aa {
 
-__host__ __device__ inline int cgx_lds_bytes(int bm, int bn) { return cgd_lds_bytes(bm, bn, 64, 2); }
+__host__ __device__ inline int cgx_lds_bytes(int bm, int bn) { return cgd_lds_bytes(bm, bn, 64, 2); }   // (= four stages of 32)
 
 // DP3 / DP0 / DP1: LDS-DMA pieces (per wave) of the tile after next issued under sub-step 3 of a K step and under
 // sub-steps 0 / 1 of the following one (the rest under sub-step 2); activations first (they may come from HBM).
-template <typename T, int BM, int BN, int WM, int WN, int DP3, int DP0, int DP1>
+//
+// BK = 32 ("deep ring"): four stages of 32 K each.  Stage s is multiplied in two sub-steps; once the fragments of its second
+// sub-step are in registers its LDS slot is free, so with one barrier per stage the slots hold stages s+1 .. s+4: THREE
+// stages (96 KB at 256 x 256) are in flight while one is multiplied, every piece has two stage times to land, and the wait
+// in front of a barrier is a counted vmcnt (the two youngest stages stay in flight).  The 2-stage BK = 64 ring has one tile
+// in flight for about half of each K step: its operand stream is latency-bound (measured: the DMA stream alone takes as
+// long as the MFMA stream alone, r03 ablation).  DP3 = pieces of stage s+4 issued under the second sub-step of stage s
+// (the rest go out under the first sub-step of stage s+1).
+template <typename T, int BM, int BN, int WM, int WN, int BK, int DP3, int DP0, int DP1>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv_gemm_x_kernel(const AaConvGemm p, const int M, const int tiles_n, const int m_begin, const int k_splits) {
-    constexpr int BK = 64, STAGES = 2;
+    constexpr int STAGES = BK == 64 ? 2 : 4;
     constexpr int NW = WM * WN;
     constexpr int MI = BM / WM / 32;     // 32-row accumulator blocks per wave
     constexpr int NI = BN / WN / 32;     // 32-column accumulator blocks per wave
@@ -49,7 +57,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv_gemm_x_k
     constexpr int KS = BK / 16;
     static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % RPI == 0 && BN % RPI == 0, "tile shape");
     static_assert(NB <= ACC_BLOCKS && R <= NB, "accumulator file");
-    static_assert(DP2 >= 0 && DP3 >= 0 && DP0 >= 0 && DP1 >= 0 && KS == 4, "DMA schedule");
+    static_assert(BK == 64 || BK == 32, "K step");
+    static_assert(DP2 >= 0 && DP3 >= 0 && DP0 >= 0 && DP1 >= 0 && (BK == 64 || (DP0 == 0 && DP1 == 0)), "DMA schedule");
     static_assert(BN * 2 <= 1024, "bias slice");
     char* smem = dyn_smem();
     char* dummy = smem + STAGES * STAGE_BYTES;
@@ -134,12 +143,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv_gemm_x_k
         {
             const bool wrap_x = n_dx + 1 == p.kw;
             if (p.k_order) {
+                const bool half = BK == 32 && !(n_cb & 32);              // first half of a 64-channel unit: same tap
                 const bool last_tap = n_tap + 1 == taps;
-                n_cb = (n_cb & ~63) + (last_tap ? 64 : 0);
+                const int cb_unit = (n_cb & ~63) + (last_tap ? 64 : 0);
                 const int t1 = last_tap ? 0 : n_tap + 1;
                 const int y1 = last_tap ? 0 : (wrap_x ? n_dy + 1 : n_dy);
                 const int x1 = (last_tap || wrap_x) ? 0 : n_dx + 1;
-                n_tap = t1; n_dy = y1; n_dx = x1;
+                n_cb = half ? n_cb + 32 : cb_unit;
+                n_tap = half ? n_tap : t1; n_dy = half ? n_dy : y1; n_dx = half ? n_dx : x1;
             } else {
                 const bool last_c = n_cb + BK >= ctot;
                 n_cb = last_c ? 0 : n_cb + BK;
@@ -186,8 +197,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv_gemm_x_k
         static_for<J1 - J0>([&](auto t) __attribute__((always_inline)) { dma_piece(IntTag<J0 + decltype(t)::value>()); });
     };
 
-    // ---- fragment read addresses: row = base + (lane&31), k-slot ks*2 + (lane>>5), un-swizzled per row.  A row is 128 bytes
-    // and every stage starts on a multiple of 128, so the byte address of sub-step ks is (address of sub-step 0) ^ (ks << 5):
+    // ---- fragment read addresses: row = base + (lane&31), k-slot ks*2 + (lane>>5), un-swizzled per row.  A row is 128 (64)
+    // bytes and every stage starts on a multiple of that, so the byte address of sub-step ks is (address of sub-step 0) ^ (ks << 5):
     // one register per fragment row block, the sub-step is an XOR constant inside the read statement
     const int frow = lane & 31, fh = lane >> 5;
     int a_off[MI], w_off[NI];
@@ -196,7 +207,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv_gemm_x_k
     const int prow = (frow & 3) + 4 * (frow >> 3) + 16 * ((frow >> 2) & 1);          // permuted weight rows: conv_gemm_dma.h
 #pragma unroll
     for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + prow; w_off[j] = BM * ROWB + rr * ROWB + ((fh ^ ((rr / RPB) & swm)) << 4); }
-    static_assert(ROWB == 128 && STAGE_BYTES % 128 == 0 && RPB == 2 && swm == 7, "XOR addressing of the k sub-steps");
+    static_assert(STAGE_BYTES % ROWB == 0 && ROWB % 64 == 0 && (BM * ROWB) % 256 == 0, "XOR addressing of the k sub-steps");
 
     AccFile af;
     static_for<NB>([&](auto b) __attribute__((always_inline)) { acc_zero<decltype(b)::value>(af); });
@@ -240,27 +251,69 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv_gemm_x_k
         substep(IntTag<3>(), IntTag<0>(), st_next, HAS_NEXT, IntTag<0>(), IntTag<HAS_NEXT2 ? DP3 : 0>());
     };
 
-    if (nk > 0) {
-        prepare(0, 0);
-        dma_range(IntTag<0>(), IntTag<PER_TILE>());
-        if (nk > 1) { prepare(1, 1); dma_range(IntTag<0>(), IntTag<DP3>()); }
+    auto put_bias = [&]() __attribute__((always_inline)) {       // (behind the first operand tiles: its global load would otherwise stall the first DMA issue)
         if (tid < BN / 8) {
             const int n = tile_n * BN + tid * 8;
             u32x4 b = u32x4{0u, 0u, 0u, 0u};
             if (p.bias && !p.bias_per_row && n + 8 <= p.n_out) b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
             *reinterpret_cast<u32x4*>(sBias + tid * 8) = b;
         }
-        if (nk > 1) dma_wait<DP3>(); else dma_wait<0>();
-        block_barrier();
-        static_for<R>([&](auto rd) __attribute__((always_inline)) { frag_read(smem, IntTag<0>(), IntTag<0>(), rd); });
-        lds_wait_all();
-        int kt = 0;
-        for (; kt + 2 < nk; ++kt) kstep(kt, BoolTag<true>(), BoolTag<true>());
-        if (nk >= 2) { kstep(kt, BoolTag<true>(), BoolTag<false>()); ++kt; }
-        kstep(kt, BoolTag<false>(), BoolTag<false>());
+    };
+    if constexpr (BK == 64) {
+        if (nk > 0) {
+            prepare(0, 0);
+            dma_range(IntTag<0>(), IntTag<PER_TILE>());
+            if (nk > 1) { prepare(1, 1); dma_range(IntTag<0>(), IntTag<DP3>()); }
+            put_bias();
+            if (nk > 1) dma_wait<DP3>(); else dma_wait<0>();
+            block_barrier();
+            static_for<R>([&](auto rd) __attribute__((always_inline)) { frag_read(smem, IntTag<0>(), IntTag<0>(), rd); });
+            lds_wait_all();
+            int kt = 0;
+            for (; kt + 2 < nk; ++kt) kstep(kt, BoolTag<true>(), BoolTag<true>());
+            if (nk >= 2) { kstep(kt, BoolTag<true>(), BoolTag<false>()); ++kt; }
+            kstep(kt, BoolTag<false>(), BoolTag<false>());
+        } else {
+            put_bias();
+            __syncthreads();
+        }
     } else {
-        if (tid < BN / 8) *reinterpret_cast<u32x4*>(sBias + tid * 8) = u32x4{0u, 0u, 0u, 0u};
-        __syncthreads();
+        // ---- deep ring: stage s lives in slot s % 4.  H1..H4 = stage s+1 .. s+4 exists.
+        constexpr int DPB = DP3, DPA = PER_TILE - DP3;
+        auto stage_step = [&](int s, auto h1_, auto h2_, auto h3_, auto h4_) __attribute__((always_inline)) {
+            constexpr bool H1 = decltype(h1_)::value, H2 = decltype(h2_)::value, H3 = decltype(h3_)::value, H4 = decltype(h4_)::value;
+            const char* st = smem + (s & 3) * STAGE_BYTES;
+            const char* st_next = smem + ((s + 1) & 3) * STAGE_BYTES;
+            // first sub-step: fragments of the second one; the rest of stage s+3's pieces (prepared during stage s-1)
+            substep(IntTag<0>(), IntTag<1>(), st, true, IntTag<DPB>(), IntTag<H3 ? DPA : 0>());
+            if constexpr (H1) {
+                dma_wait<PER_TILE * ((H2 ? 1 : 0) + (H3 ? 1 : 0))>();   // my pieces of stage s+1 landed; s+2 and s+3 stay in flight
+                block_barrier();                                        // everyone's did; every wave holds its last fragments of stage s
+            }
+            if constexpr (H4) prepare(s + 4, s & 3);                    // slot s % 4 is free from here on
+            substep(IntTag<1>(), IntTag<0>(), st_next, H1, IntTag<0>(), IntTag<H4 ? DPB : 0>());
+        };
+        if (nk > 0) {
+            prepare(0, 0);
+            dma_range(IntTag<0>(), IntTag<PER_TILE>());
+            if (nk > 1) { prepare(1, 1); dma_range(IntTag<0>(), IntTag<PER_TILE>()); }
+            if (nk > 2) { prepare(2, 2); dma_range(IntTag<0>(), IntTag<PER_TILE>()); }
+            if (nk > 3) { prepare(3, 3); dma_range(IntTag<0>(), IntTag<DPB>()); }
+            put_bias();
+            if (nk > 3) dma_wait<2 * PER_TILE + DPB>(); else if (nk == 3) dma_wait<2 * PER_TILE>(); else if (nk == 2) dma_wait<PER_TILE>(); else dma_wait<0>();
+            block_barrier();
+            static_for<R>([&](auto rd) __attribute__((always_inline)) { frag_read(smem, IntTag<0>(), IntTag<0>(), rd); });
+            lds_wait_all();
+            int s = 0;
+            for (; s + 4 < nk; ++s) stage_step(s, BoolTag<true>(), BoolTag<true>(), BoolTag<true>(), BoolTag<true>());
+            if (nk >= 4) { stage_step(s, BoolTag<true>(), BoolTag<true>(), BoolTag<true>(), BoolTag<false>()); ++s; }
+            if (nk >= 3) { stage_step(s, BoolTag<true>(), BoolTag<true>(), BoolTag<false>(), BoolTag<false>()); ++s; }
+            if (nk >= 2) { stage_step(s, BoolTag<true>(), BoolTag<false>(), BoolTag<false>(), BoolTag<false>()); ++s; }
+            stage_step(s, BoolTag<false>(), BoolTag<false>(), BoolTag<false>(), BoolTag<false>());
+        } else {
+            put_bias();
+            __syncthreads();
+        }
     }
     acc_settle();                                                // MFMA results visible to v_accvgpr_read
 

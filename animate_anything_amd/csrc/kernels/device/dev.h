@@ -99,6 +99,11 @@ __device__ __forceinline__ void lds_pin(u32x4& x) { asm volatile("" : "+v"(x)); 
 // kernels: no scratch, no compiler-made v_accvgpr_* (cdna guide 5.7 item 4).
 constexpr int ACC_BLOCKS = 20;
 struct AccFile { f32x16 v[ACC_BLOCKS - 16]; };
+// -DAA_X_ABLATE=bits builds a timing-only variant of the hand-scheduled kernels (scripts/x_ablate.py; results are garbage):
+// 1 = no operand DMA, 2 = no MFMA, 4 = no fragment reads
+#ifndef AA_X_ABLATE
+#define AA_X_ABLATE 0
+#endif
 #define AA_ACC_LITERAL_BLOCKS(X) \
     X(0, "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15") \
     X(1, "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31") \
@@ -136,6 +141,7 @@ __device__ __forceinline__ void acc_zero(AccFile& af) {
 // block B += W(32 x 16, MFMA "A" operand: rows -> accumulator registers) * A(16 x 32, "B" operand: columns -> lanes)
 template <int B>
 __device__ __forceinline__ void acc_mfma(AccFile& af, f16_t, const u32x4& w, const u32x4& a) {
+    if constexpr ((AA_X_ABLATE & 2) != 0) { asm volatile("" :: "v"(w), "v"(a)); return; }
     if constexpr (B < 16) {
 #define AA_X(b, ...) if constexpr (B == b) asm volatile("v_mfma_f32_32x32x16_f16 a[%c0:%c1], %2, %3, a[%c0:%c1]" ::"i"(16 * b), "i"(16 * b + 15), "v"(w), "v"(a) : __VA_ARGS__);
         AA_ACC_LITERAL_BLOCKS(AA_X)
@@ -170,6 +176,7 @@ __device__ __forceinline__ f32x16 acc_get(AccFile& af) {
 // precomputed address register per sub-step and fragment)
 template <int X>
 __device__ __forceinline__ void lds_read16_xor(u32x4& dst, const void* lds_ptr, IntTag<X>) {
+    if constexpr ((AA_X_ABLATE & 4) != 0) { asm volatile("" : "=v"(dst) : "v"(lds_ptr)); return; }
     const unsigned addr = (unsigned)(unsigned long long)lds_ptr;
     if constexpr (X == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
     else { unsigned t; asm volatile("v_xor_b32 %1, %3, %2\n\tds_read_b128 %0, %1" : "=v"(dst), "=&v"(t) : "v"(addr), "i"(X)); }
@@ -178,5 +185,6 @@ __device__ __forceinline__ void lds_read16_xor(u32x4& dst, const void* lds_ptr, 
 __device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // LDS-DMA piece with a wave-uniform byte offset on top of the per-lane one (the range check covers the per-lane part only)
 __device__ __forceinline__ void async_copy16_buf_s(const BufRsrc& r, unsigned lane_offset, unsigned uniform_offset, void* lds_wave_base) {
+    if constexpr ((AA_X_ABLATE & 1) != 0) { asm volatile("" :: "v"(lane_offset), "s"(uniform_offset)); return; }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r.v, (__attribute__((address_space(3))) void*)lds_wave_base, 16, lane_offset, uniform_offset, 0, 0);
 }

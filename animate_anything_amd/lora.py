@@ -74,18 +74,23 @@ def fold_lora_(model: nn.Module, loras: Sequence[torch.Tensor], replace_modules:
     if len(loras) % 2:
         raise ValueError("LoRA list must hold (up, down) pairs")
     targets = lora_targets(model, len(loras) // 2, replace_modules, mode)
-    done = []
+    # every pair is checked BEFORE the first weight is touched: a bad file leaves the model as it was
     for (name, m), up, down in zip(targets, loras[0::2], loras[1::2]):
         w = m.weight
         r = up.shape[1]
         if up.shape[0] != w.shape[0] or down.shape[0] != r or tuple(down.shape[1:]) != tuple(w.shape[1:]) or \
                 any(s != 1 for s in up.shape[2:]):
             raise ValueError(f"LoRA pair {tuple(up.shape)} x {tuple(down.shape)} does not fit layer {name} {tuple(w.shape)}")
-        delta = up.to(w.device, torch.float32).flatten(1) @ down.to(w.device, torch.float32).flatten(1)
-        w.add_((scale * delta).reshape(w.shape).to(w.dtype))
-        done.append(name)
-    if hasattr(model, "invalidate_caches"):
-        model.invalidate_caches()
+    done = []
+    try:
+        for (name, m), up, down in zip(targets, loras[0::2], loras[1::2]):
+            w = m.weight
+            delta = up.to(w.device, torch.float32).flatten(1) @ down.to(w.device, torch.float32).flatten(1)
+            w.add_((scale * delta).reshape(w.shape).to(w.dtype))
+            done.append(name)
+    finally:
+        if hasattr(model, "invalidate_caches"):
+            model.invalidate_caches()
     return done
 
 

@@ -195,11 +195,13 @@ class UNet3DConditionModel(nn.Module):
             self.down_blocks.append(_DOWN[kind](io, temb, norm_eps, norm_num_groups,
                                                 down=downsample_padding if i < n - 1 else None, **attn))
 
+        # (registered ahead of mid_block like the reference - unet_3d_condition_mask.py:171-172,202: LoRA files address
+        # layers by their position in named_modules(), so down_blocks -> up_blocks -> mid_block is part of the file format)
+        self.up_blocks = nn.ModuleList()
         cm = block_out_channels[-1]
         self.mid_block = UNetMidBlock3DCrossAttn(cm, temb, norm_eps, norm_num_groups, cm // hd[-1], hd[-1],
                                                  cross_attention_dim, mid_block_scale_factor)
 
-        self.up_blocks = nn.ModuleList()
         rev, rhd = list(reversed(block_out_channels)), list(reversed(hd))
         out_c = rev[0]
         self.num_upsamplers = 0

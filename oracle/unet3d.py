@@ -158,6 +158,7 @@ class UNet3DConditionModel(nn.Module):
 
         self.conv_in = nn.Conv2d(in_channels, ch0, 3, padding=1)           # :137-139
         self.conv_in2 = nn.Conv2d(5, ch0, 3, padding=1)                    # :140-142
+        self.time_proj_dim = ch0                                           # Timesteps(block_out_channels[0], True, 0) :146,156
         self.time_embedding = TimestepEmbedding(ch0, temb, cond_proj_dim=ch0)   # :149-154
         self.motion_embedding = nn.Sequential(nn.Linear(ch0, temb), nn.SiLU(), nn.Linear(temb, temb))  # :157-161 (dead)
         nn.init.zeros_(self.motion_embedding[-1].weight)
@@ -179,11 +180,13 @@ class UNet3DConditionModel(nn.Module):
                 raise ValueError(f"{kind} does not exist.")
             self.down_blocks.append(blk)
 
+        # (registered ahead of mid_block like the reference - unet_3d_condition_mask.py:171-172,202: LoRA files address
+        # layers by their position in named_modules(), so down_blocks -> up_blocks -> mid_block is part of the file format)
+        self.up_blocks = nn.ModuleList()
         cm = block_out_channels[-1]
         self.mid_block = UNetMidBlock3DCrossAttn(cm, temb, norm_eps, norm_num_groups, cm // hd[-1], hd[-1],
                                                  cross_attention_dim, mid_block_scale_factor)
 
-        self.up_blocks = nn.ModuleList()
         rev, rhd = list(reversed(block_out_channels)), list(reversed(hd))
         out_c = rev[0]
         self.num_upsamplers = 0
@@ -230,10 +233,10 @@ class UNet3DConditionModel(nn.Module):
         elif t.dim() == 0:
             t = t[None]
         t = t.to(sample.device).expand(b)
-        t_emb = sinusoid_embedding(t, self.conv_in.out_channels).to(self.dtype)    # :408-413
+        t_emb = sinusoid_embedding(t, self.time_proj_dim).to(self.dtype)    # :408-413
         if self.motion_strength and motion is not None:
             timestep_cond = sinusoid_embedding(torch.as_tensor(motion, device=sample.device),
-                                               self.conv_in.out_channels).to(self.dtype)   # :415
+                                               self.time_proj_dim).to(self.dtype)   # :415
         emb = self.time_embedding(t_emb, timestep_cond)
         emb = emb.repeat_interleave(num_frames, dim=0)                              # :420
         text = encoder_hidden_states.repeat_interleave(num_frames, dim=0)           # :421

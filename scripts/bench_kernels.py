@@ -17,6 +17,7 @@ p.add_argument("--only", default="")
 p.add_argument("--reps", type=int, default=10)
 p.add_argument("--ablate", type=int, default=0, help="AaConvGemm.debug ablation bits (1: no DMA, 2: no MFMA)")
 p.add_argument("--cfg-sweep", action="store_true", help="time every contraction shape under every forced tile shape")
+p.add_argument("--cfgs", default="", help="comma-separated tile indices the sweep is restricted to")
 a = p.parse_args()
 DT = torch.float16 if a.dtype == "fp16" else torch.bfloat16
 dev = "cuda"
@@ -41,6 +42,7 @@ def rnd(*s):
 
 from animate_anything_amd import _lib  # noqa: E402
 CFGS = list(ops.TILE_TABLE)
+ONLY_CFGS = {int(c) for c in a.cfgs.split(",") if c}
 ops.AUTOTUNE = False
 ops.DEBUG_ABLATE = a.ablate
 
@@ -52,6 +54,8 @@ def sweep(name, fn, flops, n_pad, geglu=0):
     if not a.cfg_sweep:
         return
     for i, (bm, bn, bk, st) in enumerate(CFGS):
+        if ONLY_CFGS and i not in ONLY_CFGS:
+            continue
         if n_pad % bn or (geglu and (bn // ops.TILE_TABLE.wave_cols(i)) % 64):
             continue
         lib.aa_set_tile_override(i)

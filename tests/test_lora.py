@@ -109,3 +109,113 @@ def test_text_encoder_fold_matches_injected_clip():
     ids = torch.randint(0, 100, (2, 16))
     with torch.no_grad():
         assert rel_err(a(ids)[0], b(ids)[0]) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The reference's own LoRA code as the checker: /root/reference/utils/lora.py imports cleanly here.
+# `inject_trainable_lora_extended` (:433-479) builds the wrappers, `save_lora_weight` (:569-581) writes the file,
+# `monkeypatch_or_replace_lora_extended` (:861-977) is what `inject_inferable_lora` (:482-526) runs at inference.
+import refload  # noqa: E402
+
+needs_ref = pytest.mark.skipif(not refload.have_reference(), reason="reference checkout not present")
+
+
+def _reference_lora_file(tmp_path, mark_compatible=False, r=4, seed=11):
+    """A LoRA file written by the REFERENCE for the oracle UNet, and the reference-injected model that produced it.
+    mark_compatible: give the layers that diffusers 0.24 builds from LoRACompatibleLinear / LoRACompatibleConv a subclass
+    type, so the reference skips them exactly as it does on a real diffusers model (utils/lora.py:963-965)."""
+    R = refload.load("utils/lora.py")
+    model, _ = _models()
+    if mark_compatible:
+        sub = {torch.nn.Linear: type("LoRACompatibleLinear", (torch.nn.Linear,), {}),
+               torch.nn.Conv2d: type("LoRACompatibleConv", (torch.nn.Conv2d,), {})}
+        for n, m in model.named_modules():
+            if type(m) in sub and not L._PLAIN_024.match(n):
+                m.__class__ = sub[type(m)]
+    R.inject_trainable_lora_extended(model, target_replace_module={"UNet3DConditionModel"}, r=r)
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, (R.LoraInjectedLinear, R.LoraInjectedConv2d, R.LoraInjectedConv3d)):
+            m.lora_up.weight.data = torch.randn(m.lora_up.weight.shape, generator=g) * 0.2      # (zero-initialised by the reference)
+            m.dropout = torch.nn.Identity()
+    path = str(tmp_path / "unet.pt")
+    R.save_lora_weight(model, path, target_replace_module={"UNet3DConditionModel"})
+    return R, model.eval(), path
+
+
+@needs_ref
+@pytest.mark.parametrize("mark_compatible", [False, True])
+def test_fold_equals_the_references_own_injection(tmp_path, mark_compatible):
+    """File written by the reference -> (a) the reference's inference-time loader on a fresh oracle UNet, (b) the restated
+    wrapper of oracle/lora.py, (c) the product's fold: all three must be the function the reference trained."""
+    R, trained, path = _reference_lora_file(tmp_path, mark_compatible)
+    i = unet_inputs(h=5, w=6, text_len=9)
+    run = lambda m: m(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
+    with torch.no_grad():
+        want = run(trained)
+    # (a) reference loader
+    a, _ = _models()
+    if mark_compatible:
+        for (n, m), (_, t) in zip(a.named_modules(), _models()[0].named_modules()):
+            pass
+        sub = {torch.nn.Linear: type("LoRACompatibleLinear", (torch.nn.Linear,), {}),
+               torch.nn.Conv2d: type("LoRACompatibleConv", (torch.nn.Conv2d,), {})}
+        for n, m in a.named_modules():
+            if type(m) in sub and not L._PLAIN_024.match(n):
+                m.__class__ = sub[type(m)]
+    R.monkeypatch_or_replace_lora_extended(a, torch.load(path), target_replace_module={"UNet3DConditionModel"}, r=4)
+    for m in a.modules():
+        if hasattr(m, "dropout") and hasattr(m, "lora_up"):
+            m.dropout = torch.nn.Identity()
+    with torch.no_grad():
+        assert rel_err(run(a.eval()), want) < 1e-5
+    # (c) product fold (weight space) on a plain oracle copy
+    c, _ = _models()
+    names = L.fold_lora_(c, torch.load(path))
+    with torch.no_grad():
+        assert rel_err(run(c), want) < 1e-4
+    # (b) the restated wrapper on the layers the fold reported
+    b, _ = _models()
+    olora.inject(b, names, torch.load(path))
+    with torch.no_grad():
+        assert rel_err(run(b), want) < 1e-5
+    base, _ = _models()
+    with torch.no_grad():
+        assert rel_err(run(base), want) > 1e-2
+
+
+@needs_ref
+def test_traversal_order_is_the_references(tmp_path):
+    """The adapter order in a reference-written file is the order `fold_lora_` walks: down_blocks, up_blocks, mid_block
+    (the registration order of the reference's UNet is part of the file format)."""
+    R, trained, path = _reference_lora_file(tmp_path)
+    net = UNet3DConditionModel(**TINY_UNET).eval()
+    cand = [n for n, _ in L._candidates(net, L.UNET_REPLACE)]
+    ref_names = []
+    for parent, name, child in R._find_modules(trained, {"UNet3DConditionModel"}, search_class=[R.LoraInjectedLinear, R.LoraInjectedConv2d, R.LoraInjectedConv3d]):
+        full = [n for n, m in trained.named_modules() if m is child]
+        ref_names.append(full[0])
+    assert cand == ref_names
+    first = lambda pre: next(k for k, n in enumerate(cand) if n.startswith(pre))
+    assert first("down_blocks") < first("up_blocks") < first("mid_block") < first("conv_out")
+
+
+@needs_ref
+def test_collapse_lora_is_the_fold(tmp_path):
+    """`collapse_lora` (utils/lora.py:780-815) folds W += alpha * up @ down in place for the wrappers below its target classes
+    (Attention / ResnetBlock2D / GEGLU ...): wherever it acted, the result is the product's folded weight."""
+    R, trained, path = _reference_lora_file(tmp_path)
+    folded, _ = _models()
+    L.fold_lora_(folded, torch.load(path), scale=1.0)
+    base = dict(_models()[0].named_parameters())
+    R.collapse_lora(trained, alpha=1.0)
+    got = dict(folded.named_parameters())
+    collapsed = 0
+    for n, m in trained.named_modules():
+        if isinstance(m, (R.LoraInjectedLinear, R.LoraInjectedConv2d, R.LoraInjectedConv3d)):
+            w = m.linear.weight if isinstance(m, R.LoraInjectedLinear) else m.conv.weight
+            if torch.equal(w, base[n + ".weight"]):
+                continue                                    # not below one of collapse_lora's target classes
+            assert torch.allclose(w, got[n + ".weight"], atol=1e-5), n
+            collapsed += 1
+    assert collapsed > 10
