@@ -47,3 +47,65 @@ def test_missing_library_fails_loudly(tmp_path):
         assert "no fallback backend" in str(e)
     else:
         raise AssertionError("binding a missing library must raise")
+
+
+def _device_code_object(tmp_path):
+    """The gfx950 code object inside libaa_mi355.so (clang offload bundle)."""
+    import struct
+    from animate_anything_amd import build
+    data = open(build.build(), "rb").read()
+    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert i >= 0
+    n = struct.unpack_from("<Q", data, i + 24)[0]
+    off = i + 32
+    for _ in range(n):
+        o, s, ln = struct.unpack_from("<QQQ", data, off)
+        off += 24
+        name = data[off:off + ln].decode()
+        off += ln
+        if "gfx950" in name:
+            p = tmp_path / "dev.co"
+            p.write_bytes(data[i + o:i + o + s])
+            return str(p)
+    raise AssertionError("no gfx950 code object in the library")
+
+
+def test_x_kernels_keep_hipcc_out_of_the_accumulators(tmp_path):
+    """The hand-scheduled contraction kernels (csrc/kernels/conv_gemm_x.h) name their accumulators a[0:255] literally:
+    hipcc must neither spill (scratch) nor touch accumulation registers itself.  Audit of the built code object
+    (cdna guide 5.7 item 4): per kernel no private segment, no VGPR spills, and exactly the v_accvgpr traffic the source
+    writes - 16 zeroing writes per literal block, 16 reads per block for each read-out site (epilogue(s), split-K)."""
+    import re
+    import shutil
+    import subprocess
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not shutil.which(os.path.join(tools, "llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    co = _device_code_object(tmp_path)
+    notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    meta = {}
+    for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
+        meta[m.group(2)] = tuple(int(m.group(k)) for k in (1, 3, 4, 5))
+    xk = {k: v for k, v in meta.items() if "conv_gemm_x_kernel" in k}
+    assert len(xk) >= 16                                    # 8 tiles x {fp16, bf16}
+    dis = subprocess.run([os.path.join(tools, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+    bodies = {}
+    cur = None
+    for line in dis.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            bodies[cur] = []
+        elif cur is not None:
+            bodies[cur].append(line)
+    for name, (agpr, scratch, vgpr, spills) in xk.items():
+        assert scratch == 0 and spills == 0, (name, scratch, spills)
+        waves = 8 if "ELi4ELi2E" in name else 4             # WM x WN = 4 x 2 (two waves per SIMD) or 2 x 2
+        assert vgpr <= (256 if waves == 8 else 512), (name, vgpr)
+        body = "\n".join(bodies[name])
+        literal_blocks = agpr // 16
+        assert literal_blocks in (8, 16), (name, agpr)
+        assert len(re.findall(r"v_accvgpr_write", body)) == 16 * literal_blocks, name
+        # read-out sites: split-K partials, the plain epilogue and (even column-block counts only) the GEGLU epilogue
+        assert len(re.findall(r"v_accvgpr_read", body)) in (2 * 16 * literal_blocks, 3 * 16 * literal_blocks), name
+        assert "scratch_" not in body, name
