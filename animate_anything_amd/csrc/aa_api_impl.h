@@ -90,6 +90,9 @@ static const CgCfg kCgCfgs[] = {
     {256, 256, 2, 2, 32, 4, 1, 1.50f, 0, 1}, // 41 one wave per SIMD
     {256, 320, 2, 2, 32, 4, 1, 1.50f, 0, 1}, // 42
     {256, 256, 4, 2, 32, 4, 1, 1.45f, 0, 1}, // 43 two waves per SIMD
+    // two 4-wave workgroups per CU (64x128 per wave, a[0:127]), three-slot ring: one multiplies while the other is in its epilogue
+    {128, 256, 2, 2, 32, 3, 2, 1.20f, 0, 1}, // 44
+    {256, 128, 4, 1, 32, 3, 2, 1.20f, 0, 1}, // 45
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -221,11 +224,11 @@ static void cg_launch_slab(const AaConvGemm& d, int m_begin, int m_end, void* st
     AA_LAUNCH((conv3x3_slab_kernel<T, BM, BN, WM, WN>), grid, block, cs_lds_bytes(BN), stream, d, m_end, tiles_n, m_begin);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int BK, int DP3, int DP0, int DP1>
+template <typename T, int BM, int BN, int WM, int WN, int BK, int DP3, int DP0, int DP1, int RING = (BK == 64 ? 2 : 4), int PER_CU = 1>
 static void cg_launch_x(const AaConvGemm& d, int m_begin, int m_end, int splits, void* stream) {
     const int tiles_n = d.n_pad / BN;
     const dim3 grid(((m_end - m_begin + BM - 1) / BM) * tiles_n, splits), block(64 * WM * WN);
-    AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1>), grid, block, cgx_lds_bytes(BM, BN), stream, d, m_end, tiles_n, m_begin, splits);
+    AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1, RING, PER_CU>), grid, block, cgx_lds_bytes(BM, BN, BK, RING), stream, d, m_end, tiles_n, m_begin, splits);
 }
 
 template <typename T>
@@ -275,6 +278,8 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 41: cg_launch_x<T, 256, 256, 2, 2, 32, 4, 0, 0>(d, m_begin, m_end, splits, stream); break;
         case 42: cg_launch_x<T, 256, 320, 2, 2, 32, 5, 0, 0>(d, m_begin, m_end, splits, stream); break;
         case 43: cg_launch_x<T, 256, 256, 4, 2, 32, 2, 0, 0>(d, m_begin, m_end, splits, stream); break;
+        case 44: cg_launch_x<T, 128, 256, 2, 2, 32, 3, 0, 0, 3, 2>(d, m_begin, m_end, splits, stream); break;
+        case 45: cg_launch_x<T, 256, 128, 4, 1, 32, 3, 0, 0, 3, 2>(d, m_begin, m_end, splits, stream); break;
         default: return false;
     }
     return true;
@@ -391,6 +396,20 @@ size_t aa_conv_gemm_workspace(const AaConvGemm* d) {
     if (!d || !cg_dma_ok(*d)) return 0;
     const int M = (int)((int64_t)d->n_img * d->h_out * d->w_out);
     return cg_plan(*d, M, true).workspace;
+}
+
+int aa_conv_gemm_launch_count(const AaConvGemm* d) {
+    using namespace aa;
+    if (!d) return 0;
+    if (!cg_dma_ok(*d)) return 1;
+    const int M = (int)((int64_t)d->n_img * d->h_out * d->w_out);
+    CgPlan pl = cg_plan(*d, M, d->workspace != nullptr);
+    if (pl.cfg < 0) return 0;
+    if (pl.workspace > (size_t)d->workspace_bytes) pl = cg_plan(*d, M, false);
+    if (pl.splits > 1) return 2;
+    int n = 1;
+    if (pl.m_main < M) n += 1 + (pl.tail_splits > 1 ? 1 : 0);
+    return n;
 }
 
 int aa_conv_gemm(const AaConvGemm* d, void* stream) {

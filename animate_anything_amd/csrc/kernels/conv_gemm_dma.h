@@ -86,7 +86,7 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
                 Pack8<T> o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o.e[e] = (T)v[q][e];
-                if (m_ok && nc + 8 * q + 8 <= n_cols) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o.raw;
+                if ((AA_X_ABLATE & 16) ? (o.raw[0] == 0x12345678u && m_ok) : (m_ok && nc + 8 * q + 8 <= n_cols)) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o.raw;   // (ablation build: no stores)
             }
         };
         auto block_f32 = [&](auto j_, float (&v)[2][8]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU) in fp32
@@ -121,7 +121,7 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) val[q][e] *= gelu_erf_f(gate[q][e]);
+                        for (int e = 0; e < 8; ++e) val[q][e] *= (AA_X_ABLATE & 8) ? gate[q][e] : gelu_erf_f(gate[q][e]);      // (ablation build: no GELU)
                     finish_block(j, val);
                 });
             }

@@ -24,7 +24,7 @@
 
 namespace aa {
 
-__host__ __device__ inline int cgx_lds_bytes(int bm, int bn) { return cgd_lds_bytes(bm, bn, 64, 2); }   // (= four stages of 32)
+__host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring) { return cgd_lds_bytes(bm, bn, bk, ring); }
 
 // DP3 / DP0 / DP1: LDS-DMA pieces (per wave) of the tile after next issued under sub-step 3 of a K step and under
 // sub-steps 0 / 1 of the following one (the rest under sub-step 2); activations first (they may come from HBM).
@@ -36,9 +36,15 @@ __host__ __device__ inline int cgx_lds_bytes(int bm, int bn) { return cgd_lds_by
 // in flight for about half of each K step: its operand stream is latency-bound (measured: the DMA stream alone takes as
 // long as the MFMA stream alone, r03 ablation).  DP3 = pieces of stage s+4 issued under the second sub-step of stage s
 // (the rest go out under the first sub-step of stage s+1).
-template <typename T, int BM, int BN, int WM, int WN, int BK, int DP3, int DP0, int DP1>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv_gemm_x_kernel(const AaConvGemm p, const int M, const int tiles_n, const int m_begin, const int k_splits) {
-    constexpr int STAGES = BK == 64 ? 2 : 4;
+// RING = slots of the deep ring (4, or 3 for the tiles that run two workgroups per CU: 2 x 3 x 24 KB at 128 x 256);
+// (A persistent variant - one workgroup per CU slot walking the tiles - was measured too: +-2 % on every shape, r03h; dispatching
+// 5440 empty workgroups costs 6.5 us, scripts/probe/dispatch_cost.hip.  Not kept.)
+// PER_CU = workgroups meant to be co-resident on a CU (two 4-wave workgroups drift out of phase: one multiplies while the
+// other runs its epilogue - the VALU-heavy GEGLU epilogue is as long as a K = 320 loop).
+template <typename T, int BM, int BN, int WM, int WN, int BK, int DP3, int DP0, int DP1, int RING = (BK == 64 ? 2 : 4), int PER_CU = 1>
+__global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv_gemm_x_kernel(const AaConvGemm p, const int M, const int tiles_n, const int m_begin, const int k_splits) {
+    constexpr int STAGES = RING;
+    static_assert(BK == 64 ? RING == 2 : (RING == 3 || RING == 4), "ring depth");
     constexpr int NW = WM * WN;
     constexpr int MI = BM / WM / 32;     // 32-row accumulator blocks per wave
     constexpr int NI = BN / WN / 32;     // 32-column accumulator blocks per wave
@@ -210,6 +216,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv_gemm_x_k
     static_assert(STAGE_BYTES % ROWB == 0 && ROWB % 64 == 0 && (BM * ROWB) % 256 == 0, "XOR addressing of the k sub-steps");
 
     AccFile af;
+    if constexpr (PER_CU > 1) wave_priority<2>();               // K loop above the co-resident workgroup's epilogue
     static_for<NB>([&](auto b) __attribute__((always_inline)) { acc_zero<decltype(b)::value>(af); });
 
     u32x4 fa[2][MI], fw[2][NI];
@@ -278,44 +285,58 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) conv_gemm_x_k
             __syncthreads();
         }
     } else {
-        // ---- deep ring: stage s lives in slot s % 4.  H1..H4 = stage s+1 .. s+4 exists.
+        // ---- deep ring: stage s lives in slot s % RING; after the barrier of step s the slots hold stages s+1 .. s+RING.
+        // HN = stage s+1 exists; HA = stage s+RING-1 exists (the rest of its pieces go out under the first sub-step);
+        // HB = stage s+RING exists (prepared behind the barrier, first DPB pieces under the second sub-step);
+        // NIF = stages among s+2 .. s+RING-1 that exist = stages still in flight when stage s+1 is waited for.
         constexpr int DPB = DP3, DPA = PER_TILE - DP3;
-        auto stage_step = [&](int s, auto h1_, auto h2_, auto h3_, auto h4_) __attribute__((always_inline)) {
-            constexpr bool H1 = decltype(h1_)::value, H2 = decltype(h2_)::value, H3 = decltype(h3_)::value, H4 = decltype(h4_)::value;
-            const char* st = smem + (s & 3) * STAGE_BYTES;
-            const char* st_next = smem + ((s + 1) & 3) * STAGE_BYTES;
-            // first sub-step: fragments of the second one; the rest of stage s+3's pieces (prepared during stage s-1)
-            substep(IntTag<0>(), IntTag<1>(), st, true, IntTag<DPB>(), IntTag<H3 ? DPA : 0>());
-            if constexpr (H1) {
-                dma_wait<PER_TILE * ((H2 ? 1 : 0) + (H3 ? 1 : 0))>();   // my pieces of stage s+1 landed; s+2 and s+3 stay in flight
+        auto stage_step = [&](int s, auto hn_, auto ha_, auto hb_, auto nif_) __attribute__((always_inline)) {
+            constexpr bool HN = decltype(hn_)::value, HA = decltype(ha_)::value, HB = decltype(hb_)::value;
+            constexpr int NIF = decltype(nif_)::value;
+            const char* st = smem + (s % RING) * STAGE_BYTES;
+            const char* st_next = smem + ((s + 1) % RING) * STAGE_BYTES;
+            substep(IntTag<0>(), IntTag<1>(), st, true, IntTag<DPB>(), IntTag<HA ? DPA : 0>());
+            if constexpr (HN) {
+                dma_wait<PER_TILE * NIF>();                              // my pieces of stage s+1 landed; younger stages stay in flight
                 block_barrier();                                        // everyone's did; every wave holds its last fragments of stage s
             }
-            if constexpr (H4) prepare(s + 4, s & 3);                    // slot s % 4 is free from here on
-            substep(IntTag<1>(), IntTag<0>(), st_next, H1, IntTag<0>(), IntTag<H4 ? DPB : 0>());
+            if constexpr (HB) prepare(s + RING, s % RING);              // slot s % RING is free from here on
+            substep(IntTag<1>(), IntTag<0>(), st_next, HN, IntTag<0>(), IntTag<HB ? DPB : 0>());
         };
         if (nk > 0) {
-            prepare(0, 0);
-            dma_range(IntTag<0>(), IntTag<PER_TILE>());
-            if (nk > 1) { prepare(1, 1); dma_range(IntTag<0>(), IntTag<PER_TILE>()); }
-            if (nk > 2) { prepare(2, 2); dma_range(IntTag<0>(), IntTag<PER_TILE>()); }
-            if (nk > 3) { prepare(3, 3); dma_range(IntTag<0>(), IntTag<DPB>()); }
+            // stages 0 .. RING-2 in full, the first pieces of stage RING-1 (= the second sub-step of a "stage -1")
+            static_for<RING - 1>([&](auto k_) __attribute__((always_inline)) {
+                constexpr int k = decltype(k_)::value;
+                if (nk > k) { prepare(k, k); dma_range(IntTag<0>(), IntTag<PER_TILE>()); }
+            });
+            if (nk > RING - 1) { prepare(RING - 1, RING - 1); dma_range(IntTag<0>(), IntTag<DPB>()); }
             put_bias();
-            if (nk > 3) dma_wait<2 * PER_TILE + DPB>(); else if (nk == 3) dma_wait<2 * PER_TILE>(); else if (nk == 2) dma_wait<PER_TILE>(); else dma_wait<0>();
+            if (nk > RING - 1) dma_wait<(RING - 2) * PER_TILE + DPB>();
+            else if (RING == 4 && nk == 3) dma_wait<2 * PER_TILE>();
+            else if (nk >= 2) dma_wait<PER_TILE>();                     // (nk == 2, or RING == 3 and nk == 2)
+            else dma_wait<0>();
             block_barrier();
             static_for<R>([&](auto rd) __attribute__((always_inline)) { frag_read(smem, IntTag<0>(), IntTag<0>(), rd); });
             lds_wait_all();
             int s = 0;
-            for (; s + 4 < nk; ++s) stage_step(s, BoolTag<true>(), BoolTag<true>(), BoolTag<true>(), BoolTag<true>());
-            if (nk >= 4) { stage_step(s, BoolTag<true>(), BoolTag<true>(), BoolTag<true>(), BoolTag<false>()); ++s; }
-            if (nk >= 3) { stage_step(s, BoolTag<true>(), BoolTag<true>(), BoolTag<false>(), BoolTag<false>()); ++s; }
-            if (nk >= 2) { stage_step(s, BoolTag<true>(), BoolTag<false>(), BoolTag<false>(), BoolTag<false>()); ++s; }
-            stage_step(s, BoolTag<false>(), BoolTag<false>(), BoolTag<false>(), BoolTag<false>());
+            for (; s + RING < nk; ++s) stage_step(s, BoolTag<true>(), BoolTag<true>(), BoolTag<true>(), IntTag<RING - 2>());
+            // the last RING steps: stage s+RING, then s+RING-1, ... no longer exist
+            if constexpr (RING == 4) {
+                if (nk >= 4) { stage_step(s, BoolTag<true>(), BoolTag<true>(), BoolTag<false>(), IntTag<2>()); ++s; }
+                if (nk >= 3) { stage_step(s, BoolTag<true>(), BoolTag<false>(), BoolTag<false>(), IntTag<1>()); ++s; }
+                if (nk >= 2) { stage_step(s, BoolTag<true>(), BoolTag<false>(), BoolTag<false>(), IntTag<0>()); ++s; }
+            } else {
+                if (nk >= 3) { stage_step(s, BoolTag<true>(), BoolTag<true>(), BoolTag<false>(), IntTag<1>()); ++s; }
+                if (nk >= 2) { stage_step(s, BoolTag<true>(), BoolTag<false>(), BoolTag<false>(), IntTag<0>()); ++s; }
+            }
+            stage_step(s, BoolTag<false>(), BoolTag<false>(), BoolTag<false>(), IntTag<0>());
         } else {
             put_bias();
             __syncthreads();
         }
     }
     acc_settle();                                                // MFMA results visible to v_accvgpr_read
+    if constexpr (PER_CU > 1) wave_priority<0>();
 
     const int ec = lane & 31, eh = lane >> 5;
     const int m_tile = m_begin + tile_m * BM;

@@ -181,6 +181,10 @@ __device__ __forceinline__ void lds_read16_xor(u32x4& dst, const void* lds_ptr, 
     if constexpr (X == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
     else { unsigned t; asm volatile("v_xor_b32 %1, %3, %2\n\tds_read_b128 %0, %1" : "=v"(dst), "=&v"(t) : "v"(addr), "i"(X)); }
 }
+// issue priority of this wave among the waves of its SIMD (0..3; the K loop of a workgroup runs above the epilogue of the
+// workgroup it shares the CU with, so the sparse MFMA / DMA stream never queues behind the other's VALU-dense epilogue)
+template <int P>
+__device__ __forceinline__ void wave_priority() { asm volatile("s_setprio %0" ::"n"(P)); }
 // every hand-issued fragment read has landed
 __device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // LDS-DMA piece with a wave-uniform byte offset on top of the per-lane one (the range check covers the per-lane part only)

@@ -33,6 +33,31 @@ def init(backend: str | None = None):
     return rank, world, device
 
 
+def pin_to_gpu_numa_node(device_index: int):
+    """Best effort: restrict this process to the CPUs of the NUMA node its GPU hangs off (eight ranks on a two-socket host
+    otherwise run their Python launch loops wherever the scheduler puts them).  Returns the CPU set used, or None when the
+    topology cannot be read (containers without /sys, single-node hosts: nothing to do)."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return cpus
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        pass
+    return None
+
+
 def clip_indices(num_clips: int, rank: int, world: int) -> List[int]:
     """Round-robin ownership: rank r denoises clips r, r+world, ..."""
     return list(range(rank, num_clips, world))

@@ -144,7 +144,12 @@ def _tile_candidates(d, rows):
     return out
 
 
+AUTOTUNE_EVENTS = 0      # signatures tuned by timing launches in this process (0 when the committed tile cache covers the workload)
+
+
 def _autotune(lib, d, stream, key, rows, dev):
+    global AUTOTUNE_EVENTS
+    AUTOTUNE_EVENTS += 1
     cands = _tile_candidates(d, rows)
     best = (-1, 0)
     if len(cands) > 1:

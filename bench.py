@@ -12,8 +12,12 @@ no data-path collective) and the final latents are all-gathered over RCCL once a
 `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); under torchrun `--gpus` must equal
 WORLD_SIZE.  Clip ownership / seeds / the final gather are animate_anything_amd.distributed.
 
+`--workload svd` / `--workload rgba` print the same JSON schema (with `roofline` and `cpu_baseline`) for BASELINE.json
+configs[3] (Stable-Video-Diffusion UNet, 14 frames x 576x1024) and configs[4] (the layerdiffuse RGBA path: the same UNet3D at
+16 frames x 384x384 plus its transparent-VAE add-ons, timed once per clip); the driver's default command stays configs[1].
+
 Prints ONE JSON line (rank 0).  `roofline` re-times the dominant kernel (the implicit-GEMM
-contraction, aa::conv_gemm_dma_kernel) in isolation with events on its own stream; `cpu_baseline` times the
+contraction: aa::conv_gemm_dma_kernel / conv3x3_slab_kernel / conv_gemm_x_kernel) in isolation with events on its own stream; `cpu_baseline` times the
 CPU oracle (oracle/, a restatement of the reference: "port") on BASELINE.json configs[0] (8 frames x 256x256, the
 reference's own CPU-runnable case) - a full forward, median of 3 - and quotes the one full 16x512x512 forward measured
 offline on the same class of host (profiles/r02_cpu_baseline.json).
@@ -29,7 +33,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_STEP = 44.262e12        # BASELINE.md section 2 census (2*MAC of every conv/linear/attention matmul)
+FLOP_PER_STEP = 44.262e12        # BASELINE.md section 2 census (2*MAC of every conv/linear/attention matmul), 16f x 512x512, CFG batch 2
+FLOP_TABLE = {(16, 64): 44.262e12, (16, 48): 23.932e12, (8, 32): 5.495e12}     # (frames, latent size) -> FLOP per step
 MFMA_PEAK_TFLOPS = 2500.0        # gfx950 dense bf16/fp16 (MI355X_MICROARCH.md)
 
 
@@ -51,7 +56,12 @@ def parse():
     p.add_argument("--no-tile-cache", action="store_true", help="ignore the committed tile choices (animate_anything_amd/tile_cache_gfx950.json): autotune everything")
     p.add_argument("--tile-cache", default="", help="json file with autotuned tile choices: loaded if present, written after warm-up")
     p.add_argument("--gemm-breakdown", default="", help="write a per-shape table of the contraction launches of one step")
-    return p.parse_args()
+    p.add_argument("--workload", default="unet3d", choices=["unet3d", "svd", "rgba"],
+                   help="unet3d: BASELINE configs[1] (the metric of record); svd: configs[3]; rgba: configs[4]")
+    a = p.parse_args()
+    if a.workload == "rgba" and a.size == 512:
+        a.size = 384                                          # configs[4]: 16 frames x 384 x 384 (48 x 48 latents)
+    return a
 
 
 def build_unet(dtype, device):
@@ -127,6 +137,83 @@ def cpu_baseline(reps=3):
     return out
 
 
+def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
+    """Re-time the recorded contraction calls of ONE step back to back on the current stream (the stream the kernels run on)
+    between two events, and account for them: FLOP and ALGORITHMIC bytes from the descriptors (unique input + weights +
+    output (+ residual) of every call, what a perfect kernel moves once), kernel launches from the library's own plan
+    (aa_conv_gemm_launch_count: main launch + split-off last round + split-K reduce), measured HBM bytes from the last committed
+    PMC run of the same command (profiles/r0N_traffic_pmc.json: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes -
+    bench.py cannot profile itself)."""
+    import ctypes as C
+    from animate_anything_amd import _lib
+    lib = _lib.get()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    flops = sum(2.0 * d.n_img * d.h_out * d.w_out * d.n_out * d.kh * d.kw * (d.c0 + d.c1) for d, _ in trace)
+    launches = sum(int(lib.aa_conv_gemm_launch_count(C.byref(d))) for d, _ in trace)
+    alg_bytes = 0.0
+    for d, _ in trace:
+        m = d.n_img * d.h_out * d.w_out
+        n_cols = d.n_out // 2 if d.geglu else d.n_out
+        alg_bytes += 2.0 * (d.n_img * d.h_in * d.w_in * (d.c0 + d.c1) + d.n_out * d.kh * d.kw * (d.c0 + d.c1) + m * n_cols
+                            + (m * n_cols if d.residual else 0))
+    reps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for d, _ in trace:
+        lib.aa_conv_gemm(C.byref(d), stream)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        for d, _ in trace:
+            lib.aa_conv_gemm(C.byref(d), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_ms = e0.elapsed_time(e1) / reps
+    if gemm_breakdown:
+        from collections import defaultdict
+        groups = defaultdict(lambda: [0, 0.0, 0.0, -1])
+        for d, _ in trace:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(3):
+                lib.aa_conv_gemm(C.byref(d), stream)
+            ev1.record()
+            ev1.synchronize()
+            key = (d.n_img * d.h_out * d.w_out, d.kh * d.kw * (d.c0 + d.c1), d.n_out, f"{d.kh}x{d.kw}s{d.stride}",
+                   "geglu" if d.geglu else "", "up" if d.h_virt != d.h_in else "")
+            g_ = groups[key]
+            g_[0] += 1
+            g_[1] += ev0.elapsed_time(ev1) / 3
+            g_[2] += 2.0 * key[0] * key[1] * key[2]
+            g_[3] = f"{d.tile}/{d.k_splits}" if d.k_splits else f"{d.tile}"
+        with open(gemm_breakdown, "w") as f:
+            f.write("M K N kind flags | launches total_ms TFLOP/s tile share\n")
+            tot = sum(v[1] for v in groups.values())
+            for key, v in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{key[0]:7d} {key[1]:6d} {key[2]:6d} {key[3]:6s} {key[4]:5s}{key[5]:3s} | {v[0]:3d} {v[1]:8.3f} "
+                        f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} {v[3]:>4s} {v[1] / tot * 100:5.1f}%\n")
+    ach = flops / (gemm_ms * 1e-3) / 1e12
+    traffic, tname, t_launches = None, None, None
+    for tname_ in ("r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):     # newest committed PMC measurement
+        tpath = os.path.join(ROOT, "profiles", tname_)
+        if os.path.exists(tpath):
+            rec = json.load(open(tpath))
+            fam = rec.get("contraction_kernels") or rec.get("conv_gemm_dma_kernel") or {}
+            traffic, tname, t_launches = fam.get("hbm_bytes_per_launch"), tname_, fam.get("launches_per_step")
+            break
+    traffic_step = traffic * t_launches if traffic and t_launches else None
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": f"HBM bytes per KERNEL LAUNCH of the contraction kernels, measured (PMC, profiles/{tname}: that run had "
+                            f"{t_launches} such launches per step)",
+            "kernel": "contraction kernels: aa::conv_gemm_dma_kernel / conv3x3_slab_kernel / conv_gemm_x_kernel (LDS-DMA implicit-GEMM conv / linear), all instances",
+            "kernel_launches_per_step": launches, "aa_conv_gemm_calls_per_step": len(trace),
+            "avg_kernel_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
+            "flop_per_step_in_kernel": flops, "kernel_ms_per_step": round(gemm_ms, 3),
+            "algorithmic_bytes_per_step": round(alg_bytes), "traffic_bytes_per_step": traffic_step,
+            "traffic_over_algorithmic": round(traffic_step / alg_bytes, 3) if traffic_step else None,
+            "whole_step_frac_of_peak": round(flop_step / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+
+
 def respawn_under_torchrun(a):
     """`python bench.py --gpus N` (N > 1) outside torchrun: start N ranks on this node, one per GPU."""
     import socket
@@ -140,6 +227,155 @@ def respawn_under_torchrun(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def rgba_addons(dtype, device, frames, size):
+    """The transparent-VAE add-ons of BASELINE configs[4] (reference models/layerdiffuse_VAE.py:17-177, call sites
+    train_transparent_i2v_stage2.py:400-426 and models/pipeline_stage2.py:290-318), once per clip: the latent-offset encoder on
+    the RGBA conditioning frame and the UNet384 alpha decoder on the `frames` decoded frames (seeded random weights)."""
+    from animate_anything_amd import layerdiffuse as P
+    torch.manual_seed(3)
+    with torch.device(device):
+        enc, dec = P.LatentTransparencyOffsetEncoder().to(dtype).eval(), P.UNet384().to(dtype).eval()
+    g = torch.Generator(device=device).manual_seed(5)
+    rgba = torch.rand(1, 4, size, size, generator=g, device=device).to(dtype) * 2 - 1
+    pix = torch.rand(frames, 3, size, size, generator=g, device=device).to(dtype) * 2 - 1
+    lat = torch.randn(frames, 4, size // 8, size // 8, generator=g, device=device).to(dtype)
+    res = {}
+    with torch.no_grad():
+        for name, fn in (("offset_encoder_ms", lambda: enc(rgba)), (f"alpha_decoder_{frames}_frames_ms", lambda: dec(pix, lat))):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                y = fn()
+            torch.cuda.synchronize()
+            res[name] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+            assert torch.isfinite(y).all()
+    return res
+
+
+def cpu_baseline_svd(frames):
+    """Oracle (oracle/svd.py, fp32) forward of the full SVD UNet on a BOUNDED sample of the workload: the real architecture and
+    frame count on a 24 x 32 latent grid (1/12 of the 72 x 128 tokens), CFG batch 2.  `value` = steps/s of that sample."""
+    import oracle.svd as O
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    with torch.device("meta"):
+        net = O.UNetSpatioTemporalConditionModel(in_channels=9, num_frames=frames)
+    net = net.to_empty(device="cpu").eval()
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if p_.dim() == 1 and "norm" in n_ and n_.endswith("weight"):
+                p_.fill_(1.0)
+            elif n_.endswith("mix_factor"):
+                p_.fill_(0.3)
+            else:
+                p_.uniform_(-0.03, 0.03, generator=g)
+    h, w = 24, 32
+    x = torch.randn(2, frames, 9, h, w, generator=g)
+    emb = torch.randn(2, 1, 1024, generator=g)
+    ids = torch.tensor([[6.0, 127.0, 0.02]]).repeat(2, 1)
+    ts = []
+    with torch.no_grad():
+        for _ in range(2):
+            t0 = time.perf_counter()
+            y = net(x, 1.3, emb, ids).sample
+            ts.append(time.perf_counter() - t0)
+    assert torch.isfinite(y).all()
+    dt = min(ts)
+    return dict(value=round(1.0 / dt, 5), unit="steps/s", cores=cores, kind="port",
+                sample=f"oracle SVD UNet forward fp32 on {cores} threads: full architecture, {frames} frames, 24 x 32 latents (1/12 of the "
+                       f"72 x 128 grid), CFG batch 2: {dt:.2f} s (runs {', '.join('%.2f' % t for t in ts)} s); value = steps/s OF THAT SAMPLE")
+
+
+def run_svd(a, rank, world, device):
+    """BASELINE configs[3]: Stable-Video-Diffusion path, 14 frames x 576 x 1024, bs=1 (reference models/pipeline.py:413-451 /
+    train_svd.py --eval).  One step = input assembly + UNetSpatioTemporalConditionModel forward on the CFG-doubled batch + per-frame
+    guidance + Euler update.  Same JSON schema as the UNet3D workload."""
+    from animate_anything_amd import ops
+    from animate_anything_amd.schedulers import EulerDiscreteScheduler
+    from animate_anything_amd.svd_pipeline import StableVideoDiffusionPipeline
+    from animate_anything_amd.svd_unet import UNetSpatioTemporalConditionModel
+    assert world == 1, "the SVD workload is a single-GPU side measurement"
+    dtype = torch.float16 if a.dtype == "fp16" else torch.bfloat16
+    frames, height, width = (14, 576, 1024) if (a.frames, a.size) == (16, 512) else (a.frames, a.size, a.size)
+    torch.manual_seed(0)
+    with torch.device(device):
+        unet = UNetSpatioTemporalConditionModel(in_channels=9, num_frames=frames).to(dtype).eval()
+    with torch.no_grad():
+        for n_, p_ in unet.named_parameters():
+            if n_.endswith("mix_factor"):
+                p_.fill_(0.3)
+    if a.no_tile_cache:
+        os.environ["AA_NO_TILE_CACHE"] = "1"
+    if a.tile_cache and os.path.exists(a.tile_cache):
+        ops.load_tile_cache(a.tile_cache)
+    if not a.no_graph:
+        unet.enable_graph()
+    pipe = StableVideoDiffusionPipeline(None, None, unet, EulerDiscreteScheduler())
+    g = torch.Generator(device=device).manual_seed(1234)
+    h, w, f = height // 8, width // 8, frames
+    latents = torch.randn(1, f, 4, h, w, generator=g, device=device)
+    cond = torch.randn(1, 1, 4, h, w, generator=g, device=device).repeat(1, f, 1, 1, 1).to(dtype)
+    cond = torch.cat([torch.zeros_like(cond), cond])
+    emb = torch.randn(1, 1, 1024, generator=g, device=device).to(dtype)
+    emb = torch.cat([torch.zeros_like(emb), emb])
+    mask = torch.zeros(2, f, 1, h, w, device=device, dtype=dtype)
+    mask[..., h // 4: h - h // 4, w // 4: w - w // 4] = 1
+    ids = torch.tensor([[6.0, 127.0, 0.02]], device=device).repeat(2, 1)
+    guidance = torch.linspace(1.0, 3.0, f)
+    total = a.warmup + a.steps
+    pipe.scheduler.set_timesteps(max(total, 2))
+    ts = pipe.scheduler.timesteps[:total]
+
+    def run(tsteps, x):
+        return pipe.denoise(x, emb, ids, cond, mask, guidance, tsteps)
+
+    with torch.no_grad():
+        x = run(ts[: a.warmup], latents * pipe.scheduler.init_noise_sigma) if a.warmup else latents
+        if a.tile_cache:
+            ops.save_tile_cache(a.tile_cache)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x = run(ts[a.warmup:], x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(x).all(), "non-finite latents"
+    ms = dt / a.steps * 1e3
+    # FLOP census of one step from the launches themselves: contractions from their descriptors, attention analytically
+    unet.enable_graph(False)
+    ops.TRACE = []
+    att = []
+    real_attention = ops.attention
+
+    def counting_attention(q, q0, k, k0, v, v0, heads, n_outer, n_inner, q_len, kv_len, *r, **kw):
+        att.append(4.0 * n_outer * n_inner * heads * q_len * kv_len * kw.get("head_dim", 64))
+        return real_attention(q, q0, k, k0, v, v0, heads, n_outer, n_inner, q_len, kv_len, *r, **kw)
+
+    ops.attention = counting_attention
+    with torch.no_grad():
+        run(ts[:1], latents)
+    ops.attention = real_attention
+    trace, ops.TRACE = ops.TRACE, None
+    torch.cuda.synchronize()
+    gemm_flop = sum(2.0 * d.n_img * d.h_out * d.w_out * d.n_out * d.kh * d.kw * (d.c0 + d.c1) for d, _ in trace)
+    flop_step = gemm_flop + sum(att)
+    out = {"metric": f"SVD denoising steps/sec @{f}fx{height}x{width} bs=1 (BASELINE configs[3])", "value": round(a.steps / dt, 4), "unit": "steps/s",
+           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": f"stable-video-diffusion-img2vid UNetSpatioTemporalConditionModel, 9 input channels "
+                                  f"({sum(p_.numel() for p_ in unet.parameters()) / 1e6:.0f}M params, seeded random init), {f} frames x "
+                                  f"{height}x{width}, CFG batch 2, 1 context token, Euler step, hipGraph={'off' if a.no_graph else 'on'}"},
+           "flop_per_step_executed": flop_step, "attention_flop_per_step": sum(att), "tflops_per_gpu": round(flop_step / (ms * 1e-3) / 1e12, 1),
+           "autotuned_signatures": int(ops.AUTOTUNE_EVENTS)}
+    if not a.no_roofline:
+        out["roofline"] = contraction_roofline(trace, a.gemm_breakdown, flop_step, ms)
+        out["roofline"]["traffic"] = out["roofline"]["traffic_bytes_per_step"] = out["roofline"]["traffic_over_algorithmic"] = None   # (the committed PMC run is of the UNet3D command)
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_svd(frames)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -147,6 +383,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     from animate_anything_amd import distributed as D
     rank, world, device = D.init("nccl")
+    pinned = D.pin_to_gpu_numa_node(device.index or 0) if world > 1 else None      # ranks stay on their GPU's NUMA node
+    if a.workload == "svd":
+        return run_svd(a, rank, world, device)
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if world > 1:
@@ -237,11 +476,16 @@ def main():
         other["max_abs_latent_difference_after_2_steps"] = (two[0] - two[1]).abs().max().item()
         other["latent_abs_max_after_2_steps"] = two[0].abs().max().item()
         pipe.cfg_shared_prefix = bool(a.cfg_shared_prefix)
-    flop_step = FLOP_PER_STEP - (1.641e12 if a.cfg_shared_prefix else 0.0)
+    flop_full = FLOP_TABLE.get((a.frames, lat), FLOP_PER_STEP * (a.frames + 1) / 17 * (lat / 64) ** 2)
+    flop_step = flop_full - (1.641e12 * flop_full / FLOP_PER_STEP if a.cfg_shared_prefix else 0.0)
     ms_step = dt / a.steps * 1e3
     value = world * a.steps / dt
+    if world > 1 and ops.AUTOTUNE_EVENTS and rank == 0:
+        print(f"bench.py: WARNING {ops.AUTOTUNE_EVENTS} contraction signatures were autotuned inside warm-up on rank 0 (the committed "
+              "tile cache animate_anything_amd/tile_cache_gfx950.json does not cover this library / table version)", file=sys.stderr, flush=True)
+    metric = f"UNet3D denoising steps/sec @{a.frames}fx{a.size}x{a.size} bs=1" + (" (layerdiffuse RGBA path, BASELINE configs[4])" if a.workload == "rgba" else "")
     out = {
-        "metric": "UNet3D denoising steps/sec @16fx512x512 bs=1", "value": round(value, 4), "unit": "steps/s",
+        "metric": metric, "value": round(value, 4), "unit": "steps/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"animate_anything_512_v1.02 UNet3D (1413M params, seeded random init), "
@@ -250,76 +494,24 @@ def main():
                    "clips_per_gpu": 1, "clips": num_clips, "parallelism": f"clip-sharded x{world}",
                    "collective": "none in the data path; one all_gather_into_tensor of the final latents (RCCL)" if world > 1 else "none"},
         "per_rank_ms_per_step": per_rank_ms,
-        "tflops_per_gpu": round(flop_step * (a.steps / dt) / 1e12 * (a.frames + 1) / 17 * (lat / 64) ** 2, 2),
+        "tflops_per_gpu": round(flop_step * (a.steps / dt) / 1e12, 2),
         "flop_per_step_executed": flop_step, "cfg_shared_prefix": bool(a.cfg_shared_prefix), "other_form": other,
     }
 
     if rank == 0 and not a.no_roofline:
-        # dominant kernel in isolation: record one eager step's contraction launches, replay them
-        # back-to-back on the current stream between two events (same stream the kernels run on).
+        # dominant kernel in isolation: record one eager step's contraction calls, replay them back to back
         unet.enable_graph(False)
         ops.TRACE = []
         with torch.no_grad():
             run(ts[:1], inp["latents"])
         trace, ops.TRACE = ops.TRACE, None
         torch.cuda.synchronize()
-        from animate_anything_amd import _lib
-        import ctypes as C
-        lib = _lib.get()
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        flops = sum(2.0 * d.n_img * d.h_out * d.w_out * d.n_out * d.kh * d.kw * (d.c0 + d.c1) for d, _ in trace)
-        reps = 3
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for d, _ in trace:
-            lib.aa_conv_gemm(C.byref(d), stream)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            for d, _ in trace:
-                lib.aa_conv_gemm(C.byref(d), stream)
-        e1.record()
-        torch.cuda.synchronize()
-        gemm_ms = e0.elapsed_time(e1) / reps
-        if a.gemm_breakdown:
-            from collections import defaultdict
-            groups = defaultdict(lambda: [0, 0.0, 0.0, -1])
-            for d, _ in trace:
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
-                for _ in range(3):
-                    lib.aa_conv_gemm(C.byref(d), stream)
-                ev1.record()
-                ev1.synchronize()
-                key = (d.n_img * d.h_out * d.w_out, d.kh * d.kw * (d.c0 + d.c1), d.n_out, f"{d.kh}x{d.kw}s{d.stride}",
-                       "geglu" if d.geglu else "", "up" if d.h_virt != d.h_in else "")
-                g_ = groups[key]
-                g_[0] += 1
-                g_[1] += ev0.elapsed_time(ev1) / 3
-                g_[2] += 2.0 * key[0] * key[1] * key[2]
-                g_[3] = f"{d.tile}/{d.k_splits}" if d.k_splits else f"{d.tile}"
-            with open(a.gemm_breakdown, "w") as f:
-                f.write("M K N kind flags | launches total_ms TFLOP/s tile share\n")
-                tot = sum(v[1] for v in groups.values())
-                for key, v in sorted(groups.items(), key=lambda kv: -kv[1][1]):
-                    f.write(f"{key[0]:7d} {key[1]:6d} {key[2]:6d} {key[3]:6s} {key[4]:5s}{key[5]:3s} | {v[0]:3d} {v[1]:8.3f} "
-                            f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} {v[3]:>4s} {v[1] / tot * 100:5.1f}%\n")
-        ach = flops / (gemm_ms * 1e-3) / 1e12
-        # HBM bytes per launch of the dominant kernel: PMC numbers (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-        # separate rocprofv3 passes, scripts/pmc_traffic.sh) committed under profiles/ - bench.py cannot run the
-        # profiler on itself, so `traffic` is the last committed measurement of the same command (null if absent)
-        traffic, tname = None, None
-        for tname_ in ("r02_traffic_pmc.json", "r01_traffic_pmc.json"):     # newest committed PMC measurement of this command
-            tpath = os.path.join(ROOT, "profiles", tname_)
-            if os.path.exists(tpath):
-                traffic, tname = json.load(open(tpath)).get("conv_gemm_dma_kernel", {}).get("hbm_bytes_per_launch"), tname_
-                break
-        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                           "traffic_unit": f"HBM bytes per launch (PMC, profiles/{tname})",
-                           "kernel": "aa::conv_gemm_dma_kernel (LDS-DMA implicit-GEMM conv/linear, all instances)",
-                           "launches_per_step": len(trace), "avg_launch_us": round(gemm_ms * 1e3 / len(trace), 2),
-                           "flop_per_step_in_kernel": flops, "kernel_ms_per_step": round(gemm_ms, 3),
-                           "whole_step_frac_of_peak": round(flop_step * (a.steps / dt) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+        out["roofline"] = contraction_roofline(trace, a.gemm_breakdown, flop_step, ms_step)
+    out["autotuned_signatures"] = int(ops.AUTOTUNE_EVENTS)      # 0 = every contraction signature came from the committed tile cache
+    if pinned:
+        out["cpu_affinity"] = f"{len(pinned)} CPUs of the GPU's NUMA node"
+    if a.workload == "rgba" and rank == 0:
+        out["rgba_addons"] = rgba_addons(dtype, device, a.frames, a.size)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AA_VERSION 102
+#define AA_VERSION 103
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
@@ -102,6 +102,9 @@ typedef struct AaConvGemm {
  * (few output tiles, long K: the small-M levels); 0 when it would not. */
 size_t aa_conv_gemm_workspace(const AaConvGemm* d);
 int aa_conv_gemm(const AaConvGemm* d, void* stream);
+/* Number of kernel launches aa_conv_gemm makes for this descriptor (version 103): 1, plus a launch for a split-off last
+ * round of tiles, plus split-K reduce launches - what a profiler counts per call (bench.py `roofline.kernel_launches_per_step`). */
+int aa_conv_gemm_launch_count(const AaConvGemm* d);
 
 /* Tile table of the LDS-DMA contraction kernel (what `AaConvGemm.tile` indexes): fills info[0..6] = rows, columns, wave
  * rows, wave columns, K step, ring stages, workgroups per CU of entry `idx`; returns 0, or -1 past the end of the table. */

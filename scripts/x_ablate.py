@@ -58,18 +58,20 @@ def shapes():
 
 
 SH = shapes()
-for abl in (0, 1, 2, 4, 5, 6, 7):
+import os as _os
+ABLS = [int(x) for x in _os.environ.get('X_ABLS', '0,1,2,4,5,6,7').split(',')]
+for abl in ABLS:
     lib = _lib.bind(_build.build(ablate=abl)) if abl else _lib.get()
     with _lib.use_library(lib):
         for name, fn, flops, cfgs in SH:
             for cfg in cfgs:
                 is_x = cfg >= 36
-                if not is_x and abl not in (0, 1, 2, 3):
+                if not is_x and abl not in (0, 1, 2, 3) and abl < 8:
                     continue
                 lib.aa_set_tile_override(cfg)
-                ops.DEBUG_ABLATE = 0 if is_x else abl
+                ops.DEBUG_ABLATE = 0 if is_x else (abl & 3)
                 us = timeit(fn)
                 ops.DEBUG_ABLATE = 0
                 lib.aa_set_tile_override(-1)
-                what = {0: "full", 1: "no DMA", 2: "no MFMA", 4: "no reads", 5: "no DMA, no reads", 6: "no MFMA, no reads", 7: "nothing"}.get(abl, str(abl))
+                what = {0: "full", 1: "no DMA", 2: "no MFMA", 4: "no reads", 5: "no DMA, no reads", 6: "no MFMA, no reads", 7: "nothing", 8: "no GELU", 16: "no stores", 15: "nothing, no GELU", 23: "nothing, no stores", 31: "nothing, no GELU, no stores"}.get(abl, str(abl))
                 print(f"{name:30s} cfg {cfg:2d} {what:18s} {us:9.1f} us  {flops / us / 1e6:7.1f} TF-equiv", flush=True)

@@ -256,6 +256,7 @@ inline void lds_pin(u32x4&) {}
 using std::fabs;
 inline float fabsf_(float x) { return std::fabs(x); }
 
+#define AA_X_ABLATE 0
 // accumulator file of conv_gemm_x.h: plain storage here
 constexpr int ACC_BLOCKS = 20;
 struct AccFile { f32x16 blk[ACC_BLOCKS]; };
@@ -265,6 +266,7 @@ template <int B> inline void acc_mfma(AccFile& af, bf16_t, const u32x4& w, const
 inline void acc_settle() {}
 template <int B> inline f32x16 acc_get(AccFile& af) { return af.blk[B]; }
 inline void lds_wait_all() {}
+template <int P> inline void wave_priority() {}
 template <int X>
 inline void lds_read16_xor(u32x4& dst, const void* lds_ptr, IntTag<X>) {
     // (address ^ X) relative to the LDS base: the emulator's LDS buffer is 16-byte aligned only, so XOR the offset

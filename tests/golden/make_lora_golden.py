@@ -25,8 +25,11 @@ R.inject_trainable_lora_extended(model, target_replace_module={"UNet3DConditionM
 g = torch.Generator().manual_seed(21)
 for m in model.modules():
     if isinstance(m, (R.LoraInjectedLinear, R.LoraInjectedConv2d, R.LoraInjectedConv3d)):
-        m.lora_up.weight.data = (torch.randn(m.lora_up.weight.shape, generator=g) * 0.3).half().float()
-        m.lora_down.weight.data = m.lora_down.weight.data.half().float()
+        # magnitudes of a trained adapter: the update is a fraction of the base weight (the reference initialises down ~ N(0, 1/r^2)
+        # and up = 0; a 0.3 x N(0, 1/r^2) product on every one of 578 layers overflows fp16 activations on the GPU side)
+        fan_in = m.lora_down.weight[0].numel()
+        m.lora_up.weight.data = (torch.randn(m.lora_up.weight.shape, generator=g) * 0.2).half().float()
+        m.lora_down.weight.data = (torch.randn(m.lora_down.weight.shape, generator=g) * 0.2 / fan_in ** 0.5).half().float()
         m.dropout = torch.nn.Identity()
 tmp = os.path.join(HERE, "_lora_tmp.pt")
 R.save_lora_weight(model, tmp, target_replace_module={"UNet3DConditionModel"})

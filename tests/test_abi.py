@@ -100,8 +100,10 @@ def test_x_kernels_keep_hipcc_out_of_the_accumulators(tmp_path):
             bodies[cur].append(line)
     for name, (agpr, scratch, vgpr, spills) in xk.items():
         assert scratch == 0 and spills == 0, (name, scratch, spills)
-        waves = 8 if "ELi4ELi2E" in name else 4             # WM x WN = 4 x 2 (two waves per SIMD) or 2 x 2
-        assert vgpr <= (256 if waves == 8 else 512), (name, vgpr)
+        m = re.search(r"x_kernelI\w+?Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        wm, wn, per_cu = int(m.group(3)), int(m.group(4)), int(m.group(10))
+        waves_per_simd = wm * wn * per_cu // 4             # 1: the whole 512-register file per lane; 2: half of it
+        assert vgpr <= 512 // waves_per_simd, (name, vgpr)
         body = "\n".join(bodies[name])
         literal_blocks = agpr // 16
         assert literal_blocks in (8, 16), (name, agpr)

@@ -219,3 +219,41 @@ def test_collapse_lora_is_the_fold(tmp_path):
             assert torch.allclose(w, got[n + ".weight"], atol=1e-5), n
             collapsed += 1
     assert collapsed > 10
+
+
+@pytest.mark.gpu
+def test_gpu_fold_matches_the_reference_written_golden():
+    """`-m gpu`: the product UNet on the GPU (fp16, graph on), one forward to build its packed-weight /
+    graph caches, then `inject_inferable_lora` on a file whose adapters and expected output were written by the REFERENCE's
+    own utils/lora.py on the oracle (tests/golden/make_lora_golden.py) - the stale-cache path included."""
+    import os
+    from util import SMALL_UNET
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lora_small_unet.pt"))
+    torch.manual_seed(0)
+    ref = oracle.UNet3DConditionModel(**SMALL_UNET).eval()
+    state = seeded_state(ref)
+    net = UNet3DConditionModel(**SMALL_UNET).eval()
+    net.load_state_dict(state)
+    net = net.half().cuda()
+    net.enable_graph()
+    i = unet_inputs(**gold["inputs"])
+    dev = lambda t: t.half().cuda()
+    call = lambda: net(dev(i["sample"]), i["t"], dev(i["text"]), dev(i["cond"]), dev(i["mask"]), motion=i["motion"]).sample.float().cpu()
+    with torch.no_grad():
+        before = call()
+        before2 = call()                                    # (graph replay)
+    assert rel_err(before2, before) < 1e-3
+
+    class Pipe:
+        unet, text_encoder = net, None
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        torch.save([t.float() for t in gold["loras"]], os.path.join(d, "1000_unet.pt"))
+        done = L.inject_inferable_lora(Pipe, d, r=gold["r"])
+    assert len(done["unet"]) == len(gold["loras"]) // 2
+    with torch.no_grad():
+        got = call()
+        got2 = call()
+    want = gold["expected"]
+    assert rel_err(got, want) < 3e-2 and rel_err(got2, want) < 3e-2
+    assert rel_err(before, want) > 5e-2                     # stale caches would reproduce `before`
