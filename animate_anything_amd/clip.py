@@ -140,7 +140,7 @@ class CLIPTextModel(nn.Module):
         return super().load_state_dict(state_dict, strict=strict, **k)
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **overrides):
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, variant=None, **overrides):
         """transformers directory layout: config.json + model.safetensors / pytorch_model.bin."""
         root = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(root, cls.config_name)) as f:
@@ -148,12 +148,8 @@ class CLIPTextModel(nn.Module):
         cfg = dict(cfg.get("text_config") or {}, **{k: v for k, v in cfg.items() if k != "text_config"})
         cfg.update(overrides)
         model = cls(**cfg)
-        st = os.path.join(root, "model.safetensors")
-        if os.path.exists(st):
-            from safetensors.torch import load_file
-            state = load_file(st)
-        else:
-            state = torch.load(os.path.join(root, "pytorch_model.bin"), map_location="cpu")
+        from ._ckpt import load_state
+        state = load_state(root, "model", variant, "pytorch_model")
         model.load_state_dict(state)
         return model.to(torch_dtype) if torch_dtype is not None else model
 
@@ -251,19 +247,15 @@ class CLIPVisionModelWithProjection(nn.Module):
         return super().load_state_dict(state_dict, strict=strict, **k)
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **overrides):
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, variant=None, **overrides):
         root = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(root, cls.config_name)) as f:
             cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
         cfg = dict(cfg.get("vision_config") or {}, **{k: v for k, v in cfg.items() if k != "vision_config"})
         cfg.update(overrides)
         model = cls(**cfg)
-        st = os.path.join(root, "model.safetensors")
-        if os.path.exists(st):
-            from safetensors.torch import load_file
-            state = load_file(st)
-        else:
-            state = torch.load(os.path.join(root, "pytorch_model.bin"), map_location="cpu")
+        from ._ckpt import load_state
+        state = load_state(root, "model", variant, "pytorch_model")
         model.load_state_dict(state)
         return model.to(torch_dtype) if torch_dtype is not None else model
 

@@ -111,6 +111,7 @@ static bool cg_slab_ok(const AaConvGemm& d, const CgCfg& c) {
 }
 
 // The hand-scheduled tiles (conv_gemm_x.h) do not carry the nearest-neighbour resize of Upsample2D.
+static thread_local unsigned g_x_disabled = 0;   // bit i: table entry 36 + i is not offered (aa_set_tile_override(-100 - mask): bisecting aid)
 static bool cg_x_ok(const AaConvGemm& d) { return d.h_virt == d.h_in && d.w_virt == d.w_in && !(d.debug & 8); }
 
 static int cg_choose(const AaConvGemm& d, int M) {
@@ -122,7 +123,7 @@ static int cg_choose(const AaConvGemm& d, int M) {
         if (d.n_pad % c.bn) continue;
         if (d.geglu && (c.bn / c.wn) % 64) continue;          // value / gate blocks pair up inside one wavefront
         if (c.slab && !cg_slab_ok(d, c)) continue;
-        if (c.x && !cg_x_ok(d)) continue;
+        if (c.x && (!cg_x_ok(d) || (i >= 36 && ((g_x_disabled >> (i - 36)) & 1u)))) continue;
         if (forced == i) return i;
         const double tiles = (double)((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
         const double slots = 256.0 * c.per_cu;
@@ -385,10 +386,13 @@ int aa_conv_gemm_tile_ok(const AaConvGemm* d, int idx) {
     if (d->n_pad % c.bn) return 0;
     if (d->geglu && (c.bn / c.wn) % 64) return 0;
     if (c.slab && !cg_slab_ok(*d, c)) return 0;
-    if (c.x && !cg_x_ok(*d)) return 0;
+    if (c.x && (!cg_x_ok(*d) || (idx >= 36 && ((g_x_disabled >> (idx - 36)) & 1u)))) return 0;
     return 1;
 }
-void aa_set_tile_override(int cfg) { aa::g_tile_override = cfg < 0 ? -1 : cfg; }
+void aa_set_tile_override(int cfg) {
+    if (cfg <= -100) { aa::g_x_disabled = (unsigned)(-100 - cfg); return; }     // bisecting aid: withdraw hand-scheduled tiles (bit i = entry 36 + i)
+    aa::g_tile_override = cfg < 0 ? -1 : cfg;
+}
 const char* aa_last_error(void) { return aa::g_err; }
 
 size_t aa_conv_gemm_workspace(const AaConvGemm* d) {

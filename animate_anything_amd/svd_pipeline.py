@@ -128,9 +128,9 @@ class StableVideoDiffusionPipeline:
         from .svd_unet import UNetSpatioTemporalConditionModel
         from .svd_vae import AutoencoderKLTemporalDecoder
         if unet is None:
-            unet = UNetSpatioTemporalConditionModel.from_pretrained(path, subfolder="unet", torch_dtype=torch_dtype)
+            unet = UNetSpatioTemporalConditionModel.from_pretrained(path, subfolder="unet", torch_dtype=torch_dtype, variant=variant)
         if vae is None:
-            vae = AutoencoderKLTemporalDecoder.from_pretrained(path, subfolder="vae", torch_dtype=torch_dtype)
+            vae = AutoencoderKLTemporalDecoder.from_pretrained(path, subfolder="vae", torch_dtype=torch_dtype, variant=variant)
         if scheduler is None:
             cfg_path = os.path.join(path, "scheduler", "scheduler_config.json")
             scheduler = EulerDiscreteScheduler.from_config(json.load(open(cfg_path)) if os.path.exists(cfg_path) else {})
@@ -138,7 +138,7 @@ class StableVideoDiffusionPipeline:
         if image_encoder is None:
             try:
                 from .clip import CLIPVisionModelWithProjection
-                image_encoder = CLIPVisionModelWithProjection.from_pretrained(path, subfolder="image_encoder", torch_dtype=torch_dtype)
+                image_encoder = CLIPVisionModelWithProjection.from_pretrained(path, subfolder="image_encoder", torch_dtype=torch_dtype, variant=variant)
             except Exception:      # optional: callers may pass image_embeddings
                 pass
         return cls(vae, image_encoder, unet, scheduler, feature_extractor)
@@ -213,6 +213,16 @@ class StableVideoDiffusionPipeline:
     def _encode_vae_image(self, image, device, num_videos_per_prompt, do_classifier_free_guidance):
         """diffusers `_encode_vae_image`: latent_dist.mode() (NOT scaled); the unconditional half is zeros, placed first."""
         lat = self.vae.encode(image.to(device)).latent_dist.mode()
+        # The reference upcasts a half-precision VAE to fp32 for this call when `config.force_upcast` is set (pipeline.py:373-383):
+        # the point is range, not precision - fp16 activations of the encoder can overflow at 576 x 1024.  The HIP kernels keep
+        # half-precision STORAGE with fp32 accumulation, so the guard here is: fp16 first; if anything overflowed, once more with
+        # bf16 storage (fp32's exponent range).  One host sync per clip.
+        if (self.vae.dtype == torch.float16 and getattr(self.vae.config, "force_upcast", False) and not bool(torch.isfinite(lat).all())):
+            self.vae.to(torch.bfloat16)
+            try:
+                lat = self.vae.encode(image.to(device, torch.bfloat16)).latent_dist.mode().to(torch.float16)
+            finally:
+                self.vae.to(torch.float16)
         if do_classifier_free_guidance:
             lat = torch.cat([torch.zeros_like(lat), lat])
         return lat.repeat(num_videos_per_prompt, 1, 1, 1)
@@ -296,7 +306,9 @@ class StableVideoDiffusionPipeline:
                                       next_t_value=ts[i + 1] if nxt else t, next_scale=sess.inputs["scale"],
                                       next_scale_value=sched.input_scale(sched.index_for_timestep(ts[i + 1])) if nxt else 1.0)
             if callback is not None:
-                callback(i, t, x)
+                new = callback(i, t, x)                          # the reference takes `latents` back from the callback (pipeline.py:445-447)
+                if new is not None and new is not x:
+                    x.copy_(new.to(x.dtype))
         return x.clone()
 
     def _denoise_generic(self, latents, image_embeddings, added_time_ids, condition_latent, mask, guidance_scale, timesteps,
@@ -311,7 +323,9 @@ class StableVideoDiffusionPipeline:
         for i, t in enumerate(timesteps):
             xin = torch.cat([x] * 2) if cfg else x
             xin = sched.scale_model_input(xin, t).to(dt)
-            parts = ([mask.to(dt).expand(xin.shape[0], -1, -1, -1, -1)] if mask is not None else []) + [xin, condition_latent.to(dt)]
+            # (the Mask pipeline hands a mask of batch 2 for the guidance pair, also when guidance is off: row b uses mask b % Bm)
+            mk = mask.to(dt)[torch.arange(xin.shape[0], device=mask.device) % mask.shape[0]] if mask is not None else None
+            parts = ([mk] if mk is not None else []) + [xin, condition_latent.to(dt)]
             v = unet(torch.cat(parts, dim=2), t, encoder_hidden_states=image_embeddings.to(dt), added_time_ids=added_time_ids,
                      return_dict=False)[0].float()
             if cfg:
@@ -319,7 +333,9 @@ class StableVideoDiffusionPipeline:
                 v = vu + g * (vc - vu)
             x = sched.step(v, t, x).prev_sample
             if callback is not None:
-                callback(i, t, x)
+                new = callback(i, t, x)
+                if new is not None:
+                    x = new.to(x.dtype)
         return x
 
     # ------------------------------------------------------------------ shared body of the two reference __call__s
@@ -370,7 +386,8 @@ class StableVideoDiffusionPipeline:
         cb = None
         if callback_on_step_end is not None:
             def cb(i, t, x):
-                callback_on_step_end(self, i, t, {"latents": x})
+                outputs = callback_on_step_end(self, i, t, {"latents": x})
+                return outputs.pop("latents", x) if isinstance(outputs, dict) else None
         x = self.denoise(latents, image_embeddings, added_time_ids, condition_latent, mask5,
                          guidance[0].float() if do_cfg else None, timesteps, cb)
         latents = x.to(dt)

@@ -410,16 +410,12 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         return cls(**{k: v for k, v in cfg.items() if k in ok})
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **overrides):
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, variant=None, **overrides):
         root = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(root, cls.config_name)) as f:
             model = cls.from_config(json.load(f), **overrides)
-        st = os.path.join(root, "diffusion_pytorch_model.safetensors")
-        if os.path.exists(st):
-            from safetensors.torch import load_file
-            state = load_file(st)
-        else:
-            state = torch.load(os.path.join(root, "diffusion_pytorch_model.bin"), map_location="cpu")
+        from ._ckpt import load_state
+        state = load_state(root, "diffusion_pytorch_model", variant)
         model.load_state_dict(state)
         return model.to(torch_dtype) if torch_dtype is not None else model
 

@@ -207,7 +207,7 @@ class AutoencoderKL(nn.Module):
         self.use_slicing = False
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **overrides):
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, variant=None, **overrides):
         root = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(root, cls.config_name)) as f:
             cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
@@ -215,12 +215,8 @@ class AutoencoderKL(nn.Module):
         import inspect
         ok = set(inspect.signature(cls.__init__).parameters) - {"self", "_"}
         model = cls(**{k: v for k, v in cfg.items() if k in ok})
-        st = os.path.join(root, "diffusion_pytorch_model.safetensors")
-        if os.path.exists(st):
-            from safetensors.torch import load_file
-            state = load_file(st)
-        else:
-            state = torch.load(os.path.join(root, "diffusion_pytorch_model.bin"), map_location="cpu")
+        from ._ckpt import load_state
+        state = load_state(root, "diffusion_pytorch_model", variant)
         model.load_state_dict(state)
         return model.to(torch_dtype) if torch_dtype is not None else model
 

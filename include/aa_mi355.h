@@ -116,7 +116,9 @@ int aa_conv_gemm_tile_ok(const AaConvGemm* d, int idx);
 
 /* Tuning / test aid: force tile shape `cfg` (index into the table in csrc/aa_api_impl.h) for every
  * following aa_conv_gemm call OF THE CALLING THREAD whose packed width it divides; cfg < 0 restores the automatic
- * choice (thread-local, like aa_last_error: the library keeps no process-global mutable state). */
+ * choice (thread-local, like aa_last_error: the library keeps no process-global mutable state).
+ * cfg <= -100 (version 103, bisecting aid): withdraw hand-scheduled tiles from every later choice of the calling thread -
+ * bit i of (-100 - cfg) stands for table entry 36 + i; -100 offers them all again. */
 void aa_set_tile_override(int cfg);
 
 /* ----------------------------------------------------------------------------------------------

@@ -4,9 +4,9 @@ OUT=gpurun_out/r03z
 mkdir -p $OUT
 export TMPDIR=/tmp
 TC=$OUT/tile_cache.json
-timeout 1500 python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-roofline --no-other-form --tile-cache $TC > $OUT/tune_unet3d.log 2>&1; echo "tune unet3d rc=$?" >> $OUT/summary.log
+timeout 1500 python bench.py --steps 5 --warmup 3 --no-cpu-baseline --tile-cache $TC > $OUT/tune_unet3d.log 2>&1; echo "tune unet3d rc=$?" >> $OUT/summary.log
 timeout 1500 python bench.py --workload svd --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --tile-cache $TC > $OUT/tune_svd.log 2>&1; echo "tune svd rc=$?" >> $OUT/summary.log
-timeout 1500 python bench.py --workload rgba --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-other-form --tile-cache $TC > $OUT/tune_rgba.log 2>&1; echo "tune rgba rc=$?" >> $OUT/summary.log
+timeout 1500 python bench.py --workload rgba --steps 3 --warmup 2 --no-cpu-baseline --tile-cache $TC > $OUT/tune_rgba.log 2>&1; echo "tune rgba rc=$?" >> $OUT/summary.log
 cp $TC animate_anything_amd/tile_cache_gfx950.json
 timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; echo "gpu tests rc=$?" >> $OUT/summary.log
 tail -3 $OUT/gpu_tests.log

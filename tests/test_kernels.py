@@ -401,7 +401,7 @@ def test_rowvec_is_a_column_slice_of_a_wider_matrix(backend):
     close(y, nhwc(ref))
 
 
-@pytest.mark.parametrize("big", [4, 30])
+@pytest.mark.parametrize("big", [4, 30, 37, 39, 42])
 def test_sparse_last_round_is_split_to_small_tiles(backend, big):
     """Big-tile launches (one per CU: 256x320; two per CU: 128x320) hand a sparsely filled last round of tiles to a small-tile
     launch (m_begin path)."""
@@ -421,7 +421,7 @@ def test_sparse_last_round_is_split_to_small_tiles(backend, big):
     close(y, nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1)).half().float() + res.float())
 
 
-@pytest.mark.parametrize("cfg,N", [(4, 320), (14, 320), (3, 256)])
+@pytest.mark.parametrize("cfg,N", [(4, 320), (14, 320), (3, 256), (39, 320), (42, 320), (36, 256), (40, 256), (43, 256)])
 def test_sparse_last_round_with_long_k_is_split_along_k(backend, cfg, N):
     """With a long K loop the leftover tiles of a big-tile launch keep the big tile and are split along K (partials of
     the tail rows only, reduce over [m_begin, M)) instead of going to small tiles."""

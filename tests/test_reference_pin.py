@@ -105,3 +105,131 @@ def test_named_modules_order_is_the_reference_order(ref_mod):
     assert leaf(ref) == leaf(orc)
     first = lambda names, pre: next(i for i, n in enumerate(names) if n.startswith(pre))
     assert first(leaf(ref), "down_blocks") < first(leaf(ref), "up_blocks") < first(leaf(ref), "mid_block")
+
+
+# --------------------------------------------------------------------------------------------- pipeline loop, helpers
+class _StepOut:
+    def __init__(self, prev_sample):
+        self.prev_sample = prev_sample
+
+
+class _SchedulerAdapter:
+    """diffusers calling convention (`step(...).prev_sample`, `scale_model_input`, `set_timesteps(n, device=)`) around the
+    oracle's DPM-Solver++ restatement."""
+    order = 1
+
+    def __init__(self):
+        import oracle
+        self.inner = oracle.DPMSolverMultistepScheduler()
+
+    def set_timesteps(self, n, device=None):
+        self.inner.set_timesteps(n)
+        self.timesteps = self.inner.timesteps
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def step(self, eps, t, x, **kw):
+        return _StepOut(self.inner.step(eps, t, x))
+
+
+def test_reference_pipeline_call_equals_oracle_pipeline(ref_mod):
+    """The reference's own `LatentToVideoPipeline.__call__` (models/pipeline.py:14-214: guidance batching, condition-latent
+    duplication, the permute / reshape around `scheduler.step`, callback cadence) run on the stub base class with oracle parts
+    == `oracle.LatentToVideoPipeline` on the same inputs, with and without guidance."""
+    import oracle
+    import models.pipeline as P                       # the reference file (sys.path set up by the ref_mod fixture)
+    assert P.__file__.startswith(REF)
+    torch.manual_seed(0)
+    unet = oracle.UNet3DConditionModel(**TINY_UNET).eval()
+    unet.load_state_dict(seeded_state(unet))
+    g = torch.Generator().manual_seed(9)
+    r = lambda *s: torch.randn(*s, generator=g)
+    frames, h, w, steps = 3, 8, 8, 4
+    x0, noise, pos, neg = r(1, 4, 1, h, w) * 0.5, r(1, 4, frames, h, w), r(1, 7, 64), r(1, 7, 64)
+    mask = torch.zeros(1, 1, 1, h, w)
+    mask[..., 2:6, 2:6] = 1
+    for guidance in (9.0, 1.0):
+        osched = oracle.DPMSolverMultistepScheduler()
+        osched.set_timesteps(steps)
+        init = oracle.ddpm_add_noise(x0.repeat(1, 1, frames, 1, 1), noise, int(osched.timesteps[0]))
+        seen_o, seen_r = [], []
+        _, want = oracle.LatentToVideoPipeline(None, unet, osched)(
+            latents=init, prompt_embeds=pos, negative_prompt_embeds=neg, condition_latent=x0, mask=mask, motion=[4.0],
+            num_inference_steps=steps, guidance_scale=guidance, return_dict=False, callback=lambda i, t, l: seen_o.append(l.clone()))
+        ref_pipe = P.LatentToVideoPipeline(None, None, None, unet, _SchedulerAdapter())
+        ref_pipe.decode_latents = lambda lat: torch.zeros(1, 3, lat.shape[2], 8, 8)        # (the VAE is not under test here)
+        with torch.no_grad():
+            _, got = ref_pipe(height=h * 8, width=w * 8, latents=init, prompt_embeds=pos, negative_prompt_embeds=neg, condition_latent=x0, mask=mask,
+                              motion=[4.0], num_inference_steps=steps, guidance_scale=guidance, return_dict=False, output_type="pt",
+                              callback=lambda i, t, l: seen_r.append(l.clone()))
+        assert len(seen_o) == len(seen_r) == steps
+        for a, b in zip(seen_r, seen_o):
+            assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+        assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+
+
+def test_append_dims_and_offset_encoder_are_the_references(ref_mod):
+    """`_append_dims` (models/pipeline.py:216-221) against the product's; `LatentTransparencyOffsetEncoder`
+    (models/layerdiffuse_VAE.py:17-41, pure torch) against the oracle restatement on one state dict."""
+    import models.pipeline as P
+    import models.layerdiffuse_VAE as LV
+    from oracle import layerdiffuse as OL
+    from animate_anything_amd.svd_pipeline import _append_dims
+    x = torch.arange(6.0).reshape(2, 3)
+    for nd in (2, 3, 5):
+        assert torch.equal(P._append_dims(x, nd), _append_dims(x, nd))
+    with pytest.raises(ValueError):
+        _append_dims(x, 1)
+    with pytest.raises(ValueError):
+        P._append_dims(x, 1)
+    torch.manual_seed(0)
+    ref = LV.LatentTransparencyOffsetEncoder().eval()
+    orc = OL.LatentTransparencyOffsetEncoder().eval()
+    state = seeded_state(ref, rezero_std=0.05)                   # the zero-initialised last conv is re-drawn
+    ref.load_state_dict(state)
+    orc.load_state_dict(state)                                   # identical key layout
+    img = torch.rand(2, 4, 24, 40, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    with torch.no_grad():
+        a, b = ref(img), orc(img)
+    assert a.shape == b.shape == (2, 4, 3, 5)
+    assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+
+
+def test_latent_helpers_are_the_references():
+    """utils/common.py:12-20,32-48,296-300 (`tensor_to_vae_latent`, `DDPM_forward_timesteps`, `calculate_latent_motion_score`)
+    executed from the reference file itself against the oracle's and the product's host-side restatements."""
+    import oracle
+    import refload
+    from oracle import pipeline as OP
+    from animate_anything_amd import pipeline as PP
+    from util import TINY_VAE
+    C = refload.load("utils/common.py", absent=("cv2", "torchvision", "torchvision.transforms", "imageio"))
+    torch.manual_seed(0)
+    vae = oracle.AutoencoderKL(**TINY_VAE).eval()
+    vae.load_state_dict(seeded_state(vae))
+    g = torch.Generator().manual_seed(2)
+    frames = torch.rand(2, 3, 3, 16, 24, generator=g) * 2 - 1                    # [b, f, c, h, w]
+    with torch.no_grad():
+        a, b = C.tensor_to_vae_latent(frames, vae), OP.tensor_to_vae_latent(frames, vae)
+    assert a.shape == b.shape == (2, 4, 3, 8, 12) and torch.allclose(a, b, atol=1e-6)      # TINY_VAE: one downsampling level
+    lat = torch.randn(2, 4, 5, 6, 7, generator=g)
+    want = C.calculate_latent_motion_score(lat)
+    assert torch.allclose(OP.calculate_latent_motion_score(lat), want, atol=1e-6)
+    assert torch.allclose(PP.calculate_latent_motion_score(lat), want, atol=1e-6)
+
+    class Sched:                                                                 # the two members DDPM_forward_timesteps touches
+        timesteps = torch.tensor([901, 801, 701, 601, 501, 401, 301, 201, 101, 1])
+
+        def add_noise(self, x, noise, t):
+            self.seen = (x.clone(), noise.clone(), t.clone())
+            return oracle.ddpm_add_noise(x, noise, int(t[0]))
+    x0 = torch.randn(1, 4, 1, 6, 7, generator=g)
+    s = Sched()
+    torch.manual_seed(11)
+    xt, ts = C.DDPM_forward_timesteps(x0, 6, 8, s)                               # the reference draws from the global generator
+    assert list(ts) == list(Sched.timesteps[4:]) and xt.shape == (1, 4, 8, 6, 7)
+    xs, noise, t = s.seen
+    assert int(t[0]) == 501 and torch.equal(xs, x0.repeat(1, 1, 8, 1, 1))
+    xo, tso = OP.ddpm_forward_timesteps(x0, 6, 8, s, noise=noise)
+    assert list(tso) == list(ts) and torch.allclose(xo, xt, atol=1e-6)

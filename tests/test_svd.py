@@ -356,3 +356,22 @@ def test_parameter_counts_of_the_real_architectures():
     count = lambda m: sum(p.numel() for p in m.parameters())
     assert count(unet8) == 1524623082 and count(unet9) - count(unet8) == 320 * 9
     assert count(vae) == 97742847
+
+
+def test_variant_checkpoints_and_callback_latents(tmp_path):
+    """`from_pretrained(..., variant="fp16")` finds `diffusion_pytorch_model.fp16.safetensors` (the reference's SVD
+    eval loads that way, train_svd.py:806-811), and the generic denoising loop takes `latents` back from `callback_on_step_end`
+    (models/pipeline.py:445-447) and accepts a batch-2 mask when guidance is off."""
+    import os
+    from animate_anything_amd._ckpt import load_state
+    from util import SMALL_SVD_VAE
+    vae = AutoencoderKLTemporalDecoder(**SMALL_SVD_VAE)
+    d = tmp_path / "vae"
+    vae.save_pretrained(str(d))
+    os.rename(d / "diffusion_pytorch_model.safetensors", d / "diffusion_pytorch_model.fp16.safetensors")
+    with pytest.raises(FileNotFoundError):
+        AutoencoderKLTemporalDecoder.from_pretrained(str(d))
+    again = AutoencoderKLTemporalDecoder.from_pretrained(str(d), variant="fp16")
+    for k, v in vae.state_dict().items():
+        assert torch.equal(v, again.state_dict()[k])
+    assert set(load_state(str(d), "diffusion_pytorch_model", "fp16").keys()) == set(vae.state_dict().keys())
