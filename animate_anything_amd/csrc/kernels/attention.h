@@ -135,6 +135,9 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) atte
 #pragma unroll
     for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.0f; oacc[1][e] = 0.0f; }
     float m_run = 0.0f, l_run = 0.0f;           // running (lazily moved) max of the scaled scores, running sum of this half-wave's keys
+    f32x16 minus_m;                             // -m_run in every entry: the C operand that starts a score block
+#pragma unroll
+    for (int e = 0; e < 16; ++e) minus_m[e] = 0.0f;
 
     const int ntiles = (p.kv_len + KT - 1) / KT;
     const bool ragged = (p.kv_len & (KT - 1)) != 0;
@@ -151,20 +154,16 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) atte
         if (wave_active) {
             const char* sK = lds + (stages == 1 ? 0 : (kt % 3)) * TILE_BYTES;
             const char* sV = sK + KT * 128;
-            // S^T - m: the accumulators start at minus the running maximum (zero for the first tile)
-            const float acc0 = kt == 0 ? 0.0f : -m_run;
+            // S^T - m: the accumulators START at minus the running maximum (zero for the first tile) - the first MFMA of every
+            // block takes a register set that holds -m in all 16 entries as its C operand, so no accumulator is initialised per tile
             f32x16 sacc[KB];
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[kb][e] = acc0;
             // the two 32-key blocks alternate so that consecutive MFMAs never wait on each other's accumulator
 #pragma unroll
             for (int dk = 0; dk < 4; ++dk)
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
                     const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + kb * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
-                    sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], sacc[kb]);
+                    sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], dk == 0 ? minus_m : sacc[kb]);
                 }
             if (p.causal && kt * KT + KT - 1 > q0) {     // causal: keys after the query's own position (tiles that reach past the wave's first query)
                 const int qpos = q0 + ql;
@@ -185,22 +184,26 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) atte
                         if (key >= p.kv_len) sacc[kb][e] = -1.0e30f;
                     }
             }
-            // row max of (score - m): four independent chains, then a tree (a single 32-long fmax chain is pure latency)
+            // row max of (score - m): three-input maxima (v_max3_f32), independent chains per half block, then a tree
             float mx[2 * KB];
 #pragma unroll
-            for (int c = 0; c < 2 * KB; ++c) mx[c] = fmaxf(sacc[c >> 1][8 * (c & 1)], sacc[c >> 1][8 * (c & 1) + 1]);
-#pragma unroll
-            for (int e = 2; e < 8; ++e)
-#pragma unroll
-                for (int c = 0; c < 2 * KB; ++c) mx[c] = fmaxf(mx[c], sacc[c >> 1][8 * (c & 1) + e]);
+            for (int c = 0; c < 2 * KB; ++c) {
+                const f32x16& a = sacc[c >> 1];
+                const int b = 8 * (c & 1);
+                const float m0 = fmaxf(fmaxf(a[b], a[b + 1]), a[b + 2]);
+                const float m1 = fmaxf(fmaxf(a[b + 3], a[b + 4]), a[b + 5]);
+                mx[c] = fmaxf(fmaxf(m0, m1), fmaxf(a[b + 6], a[b + 7]));
+            }
             float mall = fmaxf(mx[0], mx[1]);
-            if constexpr (KB == 2) mall = fmaxf(mall, fmaxf(mx[2], mx[3]));
+            if constexpr (KB == 2) mall = fmaxf(fmaxf(mall, mx[2]), mx[3]);
             const float over = wave_max_halves(mall);
             if (kt == 0 || wave_any(over > AT_DEFER)) {
                 // move the maximum (rare after the first tiles): everything still at the old maximum - O, l and this tile's
                 // scores, which have NOT been exponentiated yet - is rescaled exactly once
                 const float delta = kt == 0 ? over : fmaxf(over, 0.0f);
                 m_run += delta;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) minus_m[e] = -m_run;
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
 #pragma unroll

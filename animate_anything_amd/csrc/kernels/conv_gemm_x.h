@@ -37,6 +37,8 @@ __host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring) {
 // long as the MFMA stream alone, r03 ablation).  DP3 = pieces of stage s+4 issued under the second sub-step of stage s
 // (the rest go out under the first sub-step of stage s+1).
 // RING = slots of the deep ring (4, or 3 for the tiles that run two workgroups per CU: 2 x 3 x 24 KB at 128 x 256);
+// (Also measured and not kept, r03i: per-wave SKEWED DMA gaps - wave w issues behind MFMAs w, w+4, ... so that the CU's address unit
+// never sees two pieces at once: 0 ... -4 %.)
 // (A persistent variant - one workgroup per CU slot walking the tiles - was measured too: +-2 % on every shape, r03h; dispatching
 // 5440 empty workgroups costs 6.5 us, scripts/probe/dispatch_cost.hip.  Not kept.)
 // PER_CU = workgroups meant to be co-resident on a CU (two 4-wave workgroups drift out of phase: one multiplies while the
@@ -251,8 +253,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         substep(IntTag<1>(), IntTag<2>(), st, true, IntTag<DP3 + DP0>(), IntTag<HAS_NEXT ? DP1 : 0>());
         substep(IntTag<2>(), IntTag<3>(), st, true, IntTag<DP3 + DP0 + DP1>(), IntTag<HAS_NEXT ? DP2 : 0>());
         if constexpr (HAS_NEXT) {
-            dma_wait<0>();                                       // my pieces of tile kt+1 landed ...
-            block_barrier();                                     // ... everyone's did, and every wave holds its last fragments of tile kt
+            if constexpr (!(AA_X_ABLATE & 64)) dma_wait<0>();    // my pieces of tile kt+1 landed ...
+            if constexpr (!(AA_X_ABLATE & 32)) block_barrier();  // ... everyone's did, and every wave holds its last fragments of tile kt
         }
         if constexpr (HAS_NEXT2) prepare(kt + 2, kt & 1);        // stage kt&1 is free from here on
         substep(IntTag<3>(), IntTag<0>(), st_next, HAS_NEXT, IntTag<0>(), IntTag<HAS_NEXT2 ? DP3 : 0>());
@@ -297,8 +299,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             const char* st_next = smem + ((s + 1) % RING) * STAGE_BYTES;
             substep(IntTag<0>(), IntTag<1>(), st, true, IntTag<DPB>(), IntTag<HA ? DPA : 0>());
             if constexpr (HN) {
-                dma_wait<PER_TILE * NIF>();                              // my pieces of stage s+1 landed; younger stages stay in flight
-                block_barrier();                                        // everyone's did; every wave holds its last fragments of stage s
+                if constexpr (!(AA_X_ABLATE & 64)) dma_wait<PER_TILE * NIF>();      // my pieces of stage s+1 landed; younger stages stay in flight
+                if constexpr (!(AA_X_ABLATE & 32)) block_barrier();                 // everyone's did; every wave holds its last fragments of stage s
             }
             if constexpr (HB) prepare(s + RING, s % RING);              // slot s % RING is free from here on
             substep(IntTag<1>(), IntTag<0>(), st_next, HN, IntTag<0>(), IntTag<HB ? DPB : 0>());

@@ -3,6 +3,7 @@
 library and under the -DAA_X_ABLATE variants (no DMA / no MFMA / no fragment reads; results are garbage, only
 the time matters) - and the compiled 8-wave kernel with its runtime ablation bits for comparison."""
 import os
+import os as _os
 import sys
 
 import torch
@@ -58,7 +59,11 @@ def shapes():
 
 
 SH = shapes()
-import os as _os
+if _os.environ.get('X_ONLY'):
+    SH = [t for t in SH if _os.environ['X_ONLY'] in t[0]]
+if _os.environ.get('X_CFGS'):
+    _c = tuple(int(x) for x in _os.environ['X_CFGS'].split(','))
+    SH = [(n, f, fl, _c) for n, f, fl, _ in SH]
 ABLS = [int(x) for x in _os.environ.get('X_ABLS', '0,1,2,4,5,6,7').split(',')]
 for abl in ABLS:
     lib = _lib.bind(_build.build(ablate=abl)) if abl else _lib.get()
@@ -73,5 +78,5 @@ for abl in ABLS:
                 us = timeit(fn)
                 ops.DEBUG_ABLATE = 0
                 lib.aa_set_tile_override(-1)
-                what = {0: "full", 1: "no DMA", 2: "no MFMA", 4: "no reads", 5: "no DMA, no reads", 6: "no MFMA, no reads", 7: "nothing", 8: "no GELU", 16: "no stores", 15: "nothing, no GELU", 23: "nothing, no stores", 31: "nothing, no GELU, no stores"}.get(abl, str(abl))
+                what = {0: "full", 1: "no DMA", 2: "no MFMA", 4: "no reads", 5: "no DMA, no reads", 6: "no MFMA, no reads", 7: "nothing", 8: "no GELU", 16: "no stores", 15: "nothing, no GELU", 32: "no barrier", 64: "no DMA wait", 96: "no barrier, no DMA wait", 23: "nothing, no stores", 31: "nothing, no GELU, no stores"}.get(abl, str(abl))
                 print(f"{name:30s} cfg {cfg:2d} {what:18s} {us:9.1f} us  {flops / us / 1e6:7.1f} TF-equiv", flush=True)

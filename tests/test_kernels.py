@@ -636,3 +636,34 @@ def test_x_tiles_short_and_odd_k_ranges(backend, cfg, N, K, splits):
         ops.K_SPLITS = 0
         lib.aa_set_tile_override(-1)
     close(y, x.float() @ w.float().t() + b.float())
+
+
+@pytest.mark.parametrize("cfg,N", [(36, 256), (39, 320), (40, 256), (42, 320), (44, 256)])
+def test_x_tiles_bf16(backend, cfg, N):
+    """The hand-scheduled tiles name their MFMA opcode in an asm string per storage type: bf16 operands through
+    v_mfma_f32_32x32x16_bf16 (3x3 convolution + residual, GEGLU where the tile pairs value / gate blocks)."""
+    from animate_anything_amd import _lib
+    bf = torch.bfloat16
+    g0 = torch.Generator().manual_seed(251)
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g0) * scale).to(bf).to(DEV)
+    n, h, w, cin = 2, 9, 11, 128
+    x, wt, b = r(n, cin, h, w), r(N, cin, 3, 3, scale=0.05), r(N)
+    g = ops.conv3x3_geom(n, h, w)
+    res = r(g.rows, N)
+    lib = _lib.get()
+    lib.aa_set_tile_override(cfg)
+    try:
+        y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res)
+        yg = None
+        if N % 64 == 0 and cfg != 39 and cfg != 42:
+            M, K, D = 300, 128, N // 2 if N >= 256 else N
+            xl, wl, bl = r(M, K), r(2 * D, K, scale=0.1), r(2 * D)
+            yg = ops.conv_gemm(xl, ops.pack_weight(wl, bl, geglu=True), ops.linear_geom(M))
+    finally:
+        lib.aa_set_tile_override(-1)
+    assert y.dtype == bf
+    ref = nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1)).to(bf).float() + res.float()
+    close(y, ref, tol=4e-2)                                   # bf16 storage: 8 mantissa bits
+    if yg is not None:
+        hh = xl.float() @ wl.float().t() + bl.float()
+        close(yg, hh[:, :D] * F.gelu(hh[:, D:]), tol=4e-2)
