@@ -84,6 +84,21 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const int tile_m = logical / tiles_n;
     const int tile_n = logical - tile_m * tiles_n;
 
+    // debug bit 8 (scripts/phase_probe_x.py): thread 0 leaves stamps in workspace[bid][8]: shader clock at entry (0), before the
+    // first DMA piece (1), with the first stage landed (6), behind the K loop (2), at exit (5); 100 MHz wall clock at entry (7) and
+    // exit (4); which CU ran it (3)
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if ((p.debug & 8) && tid == 0) reinterpret_cast<long long*>(p.workspace)[(int64_t)blockIdx.x * 8 + slot] = clock_now();
+    };
+    auto stamp_wall = [&](int slot, int id_slot) __attribute__((always_inline)) {
+        if ((p.debug & 8) && tid == 0) {
+            long long* w = reinterpret_cast<long long*>(p.workspace) + (int64_t)blockIdx.x * 8;
+            w[slot] = wall_now();
+            if (id_slot >= 0) w[id_slot] = hw_id();
+        }
+    };
+    stamp(0);
+    stamp_wall(7, 3);
     const int ctot = p.c0 + p.c1;
     const int nk_all = p.k_pad / BK;
     const int k_per = (nk_all + k_splits - 1) / k_splits;
@@ -271,11 +286,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     if constexpr (BK == 64) {
         if (nk > 0) {
             prepare(0, 0);
+            stamp(1);
             dma_range(IntTag<0>(), IntTag<PER_TILE>());
             if (nk > 1) { prepare(1, 1); dma_range(IntTag<0>(), IntTag<DP3>()); }
             put_bias();
             if (nk > 1) dma_wait<DP3>(); else dma_wait<0>();
             block_barrier();
+            stamp(6);
             static_for<R>([&](auto rd) __attribute__((always_inline)) { frag_read(smem, IntTag<0>(), IntTag<0>(), rd); });
             lds_wait_all();
             int kt = 0;
@@ -307,6 +324,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         };
         if (nk > 0) {
             // stages 0 .. RING-2 in full, the first pieces of stage RING-1 (= the second sub-step of a "stage -1")
+            stamp(1);
             static_for<RING - 1>([&](auto k_) __attribute__((always_inline)) {
                 constexpr int k = decltype(k_)::value;
                 if (nk > k) { prepare(k, k); dma_range(IntTag<0>(), IntTag<PER_TILE>()); }
@@ -318,6 +336,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             else if (nk >= 2) dma_wait<PER_TILE>();                     // (nk == 2, or RING == 3 and nk == 2)
             else dma_wait<0>();
             block_barrier();
+            stamp(6);
             static_for<R>([&](auto rd) __attribute__((always_inline)) { frag_read(smem, IntTag<0>(), IntTag<0>(), rd); });
             lds_wait_all();
             int s = 0;
@@ -338,6 +357,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         }
     }
     acc_settle();                                                // MFMA results visible to v_accvgpr_read
+    stamp(2);
     if constexpr (PER_CU > 1) wave_priority<0>();
 
     const int ec = lane & 31, eh = lane >> 5;
@@ -362,6 +382,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     }
     cgd_epilogue_g<T, MI, NI>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) { return acc_get<decltype(i_)::value * NI + decltype(j_)::value>(af); },
                               m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN));
+    stamp(5);
+    stamp_wall(4, -1);
 }
 
 }  // namespace aa

@@ -41,6 +41,11 @@ __device__ __forceinline__ float wave_sum_halves(float x) {
 
 // Shader-clock timestamp (s_memtime) for the phase probe (AaConvGemm.debug bit 8).
 __device__ __forceinline__ long long clock_now() { return (long long)__builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ long long wall_now() { return (long long)__builtin_amdgcn_s_memrealtime(); }      // 100 MHz, chip-wide
+// HW_ID (wave / SIMD / CU / SH / SE of this wave) in the low word, XCC_ID in the high word
+__device__ __forceinline__ long long hw_id() {
+    return (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+}
 
 // LDS-DMA through a buffer descriptor: every lane fetches 16 bytes, the wave's 64 pieces land lane-linear at
 // lds_wave_base + lane*16 (wave-uniform base) without passing through VGPRs; operand base + range sit in SGPRs, each lane

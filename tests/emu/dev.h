@@ -221,6 +221,8 @@ inline f32x16 mfma_32x32x16(f16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma
 inline f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<bf16_t>(a, b, c); }
 
 inline long long clock_now() { static thread_local long long t = 0; return t += 64; }
+inline long long wall_now() { return clock_now(); }
+inline long long hw_id() { return 0; }
 struct BufRsrc { const char* base; unsigned bytes; };
 inline BufRsrc make_rsrc(const void* base, unsigned bytes) { return BufRsrc{static_cast<const char*>(base), bytes}; }
 inline void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_wave_base) {
