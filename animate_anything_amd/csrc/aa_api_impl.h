@@ -112,7 +112,7 @@ static bool cg_slab_ok(const AaConvGemm& d, const CgCfg& c) {
 
 // The hand-scheduled tiles (conv_gemm_x.h) do not carry the nearest-neighbour resize of Upsample2D.
 static thread_local unsigned g_x_disabled = 0;   // bit i: table entry 36 + i is not offered (aa_set_tile_override(-100 - mask): bisecting aid)
-static bool cg_x_ok(const AaConvGemm& d) { return d.h_virt == d.h_in && d.w_virt == d.w_in && !(d.debug & 8); }
+static bool cg_x_ok(const AaConvGemm& d) { return d.h_virt == d.h_in && d.w_virt == d.w_in; }
 
 static int cg_choose(const AaConvGemm& d, int M) {
     int best = -1;

@@ -36,6 +36,18 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return x / (1.0f + fast_exp2(xc * pz));
 }
 
+// the same function on two values with the packed fp32 instructions (half the multiply / fma issues; exp2 and rcp stay scalar)
+__device__ __forceinline__ f32x2 gelu_erf_2(f32x2 x) {
+    const f32x2 xc = f32x2{clamp_f(x[0], -8.0f, 8.0f), clamp_f(x[1], -8.0f, 8.0f)};
+    const f32x2 x2 = xc * xc;
+    const f32x2 c5 = f32x2{0.001014264184050262f, 0.001014264184050262f}, c3 = f32x2{-0.10677573084831238f, -0.10677573084831238f},
+                c1 = f32x2{-2.301121234893799f, -2.301121234893799f};
+    const f32x2 pz = __builtin_elementwise_fma(__builtin_elementwise_fma(c5, x2, c3), x2, c1);
+    const f32x2 t = xc * pz;
+    const f32x2 d = f32x2{fast_exp2(t[0]), fast_exp2(t[1])} + f32x2{1.0f, 1.0f};
+    return x * f32x2{fast_rcp(d[0]), fast_rcp(d[1])};
+}
+
 template <typename T>
 __device__ __forceinline__ void store_out(void* out, int out_dtype, int64_t idx, float v) {
     if (out_dtype == AA_F32) reinterpret_cast<float*>(out)[idx] = v;

@@ -36,7 +36,123 @@ __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages)
 // GEGLU (value block j, gate block j+1 sit in the same lane) and the residual are applied on the way out.
 //   m_wave  first output row of this wave's blocks          n_wave  first (packed) output column of this wave's blocks
 //   sBiasW  the bias slice of those columns in LDS
-template <typename T, int MI, int NI, typename Get>
+// ---- the same epilogue for the combinations that carry the step (plain / time-embedding row vector / residual / GEGLU),
+// without a branch inside: output, residual and row vector go through buffer descriptors whose range check drops row
+// tails (the descriptor ends behind the last valid row of this wave) and column tails (offset forced out of range), so a
+// wave runs straight through MI x NI blocks; GELU on packed fp32 pairs.  BIAS = false: the caller started the
+// accumulators from the bias.  Everything else (SiLU, per-row bias, GEGLU with a residual ...) takes cgd_epilogue_g's
+// general path below.
+template <typename T, int MI, int NI, bool GEGLU, bool RV, bool POST, bool BIAS, typename Get>
+__device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW) {
+    static_assert(!GEGLU || (NI % 2 == 0 && !RV && !POST), "GEGLU pairs value block j with gate block j + 1");
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NJ = GEGLU ? NI / 2 : NI;                 // output blocks per block row
+    const int lane = threadIdx.x & 63;
+    const int ec = lane & 31, eh = lane >> 5;
+    const int n_cols = GEGLU ? (p.n_out >> 1) : p.n_out;
+    const int rows_ok = max(0, min(MI * 32, M - m_wave));
+    const BufRsrc r_out = make_rsrc(reinterpret_cast<const T*>(p.out) + (int64_t)m_wave * p.ldo, (unsigned)(rows_ok * p.ldo) * 2u);
+    const T* resid = reinterpret_cast<const T*>(p.residual);
+    const BufRsrc r_res = make_rsrc(resid ? resid + (int64_t)m_wave * p.ldr : resid, resid ? (unsigned)(rows_ok * p.ldr) * 2u : 0u);
+    const BufRsrc r_rv = make_rsrc(p.rowvec, 0x7fffffffu);
+    const float acc_scale = p.acc_scale != 0.0f ? p.acc_scale : 1.0f;
+    const float out_scale = p.out_scale;
+    // byte offset of this lane's columns inside an output (= residual) row, per output block and 16-byte half
+    unsigned coff[NJ][2];
+#pragma unroll
+    for (int h = 0; h < NJ; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int nc = (GEGLU ? (n_wave >> 1) : n_wave) + h * 32 + 16 * eh + 8 * q;
+            coff[h][q] = nc + 8 <= n_cols ? (unsigned)nc * 2u : OOB;
+        }
+    static_for<MI>([&](auto i_) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_)::value;
+        const unsigned row = (unsigned)(i * 32 + ec);
+        const unsigned o_row = row * (unsigned)p.ldo * 2u;
+        u32x4 pre[NJ][2];                                  // the row vector (else the residual) of the whole block row, fetched up front
+        if constexpr (RV) {
+            const int mc = min(m_wave + (int)row, M - 1);
+            const unsigned rv_row = (unsigned)((mc / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out)) * 2u;
+#pragma unroll
+            for (int h = 0; h < NJ; ++h)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) pre[h][q] = buf_load16(r_rv, rv_row + coff[h][q]);
+        } else if constexpr (POST) {
+            const unsigned r_row = row * (unsigned)p.ldr * 2u;
+#pragma unroll
+            for (int h = 0; h < NJ; ++h)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) pre[h][q] = buf_load16(r_res, r_row + coff[h][q]);
+        }
+        static_for<NJ>([&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value, j = GEGLU ? 2 * h : h;
+            float v[16];
+            {
+                const f32x16 a = get(IntTag<i>(), IntTag<j>());
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = a[e];
+            }
+            if constexpr (BIAS) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    Pack8<T> b; b.raw = *reinterpret_cast<const u32x4*>(sBiasW + (j * 32 + 16 * eh + 8 * q));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[8 * q + e] += (float)b.e[e];
+                }
+            }
+            if constexpr (RV) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    Pack8<T> r; r.raw = pre[h][q];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[8 * q + e] += (float)r.e[e];
+                }
+            }
+            if constexpr (GEGLU) {
+                float g[16];
+                {
+                    const f32x16 a = get(IntTag<i>(), IntTag<j + 1>());
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) g[e] = a[e];
+                }
+                if constexpr (BIAS) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        Pack8<T> b; b.raw = *reinterpret_cast<const u32x4*>(sBiasW + ((j + 1) * 32 + 16 * eh + 8 * q));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) g[8 * q + e] += (float)b.e[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 y = (AA_X_ABLATE & 8) ? f32x2{g[e], g[e + 1]} : gelu_erf_2(f32x2{g[e], g[e + 1]});      // (ablation build: no GELU)
+                    v[e] *= y[0]; v[e + 1] *= y[1];
+                }
+            }
+            if constexpr (POST) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    Pack8<T> r;
+                    if constexpr (RV) r.raw = buf_load16(r_res, row * (unsigned)p.ldr * 2u + coff[h][q]); else r.raw = pre[h][q];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[8 * q + e] = (v[8 * q + e] * acc_scale + (float)r.e[e]) * out_scale;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                Pack8<T> o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.e[e] = (T)v[8 * q + e];
+                if constexpr ((AA_X_ABLATE & 16) != 0) { if (o.raw[0] == 0x12345678u) buf_store16(r_out, o_row + coff[h][q], o.raw); }   // (ablation build: no stores)
+                else buf_store16(r_out, o_row + coff[h][q], o.raw);
+            }
+        });
+    });
+}
+
+// BIAS_FOLDED: the accumulators were started from the bias (conv_gemm_x.h) and sBiasW holds zeros.
+template <typename T, int MI, int NI, bool BIAS_FOLDED = false, typename Get>
 __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW) {
     // get(IntTag<i>, IntTag<j>) -> the 16 accumulators of 32x32 block (i, j) of this lane (an array element, or a read-out
     // of the literal accumulation registers of conv_gemm_x.h)
@@ -51,6 +167,21 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
     const bool post = resid || p.out_scale != 1.0f || acc_scale != 1.0f;
     const bool silu = p.act == AA_ACT_SILU;
     const bool pre_is_rv = rowvec != nullptr;             // the prefetch registers carry the row vector, else the residual
+    // the combinations that carry the step take the branch-free forms - where the accumulators sit in the accumulation registers
+    // (conv_gemm_x.h): next to 128-160 accumulators in VGPRs the extra offsets spill (measured: 160-220 dwords of scratch)
+    if (BIAS_FOLDED && !silu && !p.bias_per_row) {
+        if (p.geglu) {
+            if constexpr (NI % 2 == 0) { if (!rowvec && !post) { cgd_epilogue_fast<T, MI, NI, true, false, false, !BIAS_FOLDED>(p, M, get, m_wave, n_wave, sBiasW); return; } }
+        } else if (rowvec) {
+            if (post) cgd_epilogue_fast<T, MI, NI, false, true, true, !BIAS_FOLDED>(p, M, get, m_wave, n_wave, sBiasW);
+            else cgd_epilogue_fast<T, MI, NI, false, true, false, !BIAS_FOLDED>(p, M, get, m_wave, n_wave, sBiasW);
+            return;
+        } else {
+            if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED>(p, M, get, m_wave, n_wave, sBiasW);
+            else cgd_epilogue_fast<T, MI, NI, false, false, false, !BIAS_FOLDED>(p, M, get, m_wave, n_wave, sBiasW);
+            return;
+        }
+    }
 #define AA_ZERO4 (u32x4{0u, 0u, 0u, 0u})          /* a prvalue: `c ? arr[i] : zero_variable` would select between ADDRESSES and pin arr in scratch */
     auto col_of = [&](int j) __attribute__((always_inline)) { return p.geglu ? (n_wave >> 1) + (j >> 1) * 32 + 16 * eh : n_wave + j * 32 + 16 * eh; };
     static_for<MI>([&](auto i_) __attribute__((always_inline)) {
@@ -139,7 +270,7 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
 template <typename T, int MI, int NI>
 __device__ __forceinline__ void cgd_epilogue(const AaConvGemm& p, const int M, f32x16 (&acc)[MI][NI], const int m_wave, const int n_wave,
                                              const T* sBiasW) {
-    cgd_epilogue_g<T, MI, NI>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) -> const f32x16& { return acc[decltype(i_)::value][decltype(j_)::value]; },
+    cgd_epilogue_g<T, MI, NI, false>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) -> const f32x16& { return acc[decltype(i_)::value][decltype(j_)::value]; },
                               m_wave, n_wave, sBiasW);
 }
 

@@ -234,7 +234,30 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 
     AccFile af;
     if constexpr (PER_CU > 1) wave_priority<2>();               // K loop above the co-resident workgroup's epilogue
-    static_for<NB>([&](auto b) __attribute__((always_inline)) { acc_zero<decltype(b)::value>(af); });
+    // The accumulation starts from the bias (this lane's 16 columns of every column block, the same for all row blocks): the
+    // epilogue adds nothing.  Fetched here, ahead of the first operand pieces; written into the accumulators once those are on
+    // their way.  Split-K partials and per-row biases start from zero (a descriptor of length 0 loads zeros).
+    const bool bias_folded = k_splits == 1 && !p.bias_per_row;
+    const BufRsrc r_bias = make_rsrc(p.bias, (p.bias && bias_folded) ? (unsigned)p.n_out * 2u : 0u);
+    u32x4 bias_raw[NI][2];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            bias_raw[j][q] = buf_load16(r_bias, (unsigned)(tile_n * BN + wn * (BN / WN) + j * 32 + 16 * (lane >> 5) + 8 * q) * 2u);
+    auto start_from_bias = [&]() __attribute__((always_inline)) {
+        static_for<NI>([&](auto j_) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_)::value;
+            f32x16 b;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                Pack8<T> h; h.raw = bias_raw[j][q];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b[8 * q + e] = (float)h.e[e];
+            }
+            static_for<MI>([&](auto i_) __attribute__((always_inline)) { acc_init<decltype(i_)::value * NI + j>(af, b); });
+        });
+    };
 
     u32x4 fa[2][MI], fw[2][NI];
     // read number rd of sub-step ks of the stage at `st` into fragment set `set` (order of first use: a0, w0 .. w(NI-1), a1 ..)
@@ -275,13 +298,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         substep(IntTag<3>(), IntTag<0>(), st_next, HAS_NEXT, IntTag<0>(), IntTag<HAS_NEXT2 ? DP3 : 0>());
     };
 
-    auto put_bias = [&]() __attribute__((always_inline)) {       // (behind the first operand tiles: its global load would otherwise stall the first DMA issue)
-        if (tid < BN / 8) {
-            const int n = tile_n * BN + tid * 8;
-            u32x4 b = u32x4{0u, 0u, 0u, 0u};
-            if (p.bias && !p.bias_per_row && n + 8 <= p.n_out) b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
-            *reinterpret_cast<u32x4*>(sBias + tid * 8) = b;
-        }
+    auto put_bias = [&]() __attribute__((always_inline)) {       // the general epilogue path adds a bias slice from LDS: zeros here, the
+        if (tid < BN / 8) *reinterpret_cast<u32x4*>(sBias + tid * 8) = u32x4{0u, 0u, 0u, 0u};     // accumulators already carry the bias
+        start_from_bias();
     };
     if constexpr (BK == 64) {
         if (nk > 0) {
@@ -380,7 +399,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         });
         return;
     }
-    cgd_epilogue_g<T, MI, NI>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) { return acc_get<decltype(i_)::value * NI + decltype(j_)::value>(af); },
+    cgd_epilogue_g<T, MI, NI, true>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) { return acc_get<decltype(i_)::value * NI + decltype(j_)::value>(af); },
                               m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN));
     stamp(5);
     stamp_wall(4, -1);

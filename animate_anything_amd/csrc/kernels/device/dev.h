@@ -25,6 +25,8 @@ __device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, 
 // bare v_exp_f32 (2^x): no denormal-range fix-up sequence around it - callers only pass x <= 0 and are happy with
 // results that underflow to 0.
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float clamp_f(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }   // one v_med3_f32
 __device__ __forceinline__ bool wave_any(bool pred) { return __any((int)pred) != 0; }
 // Combine a value with the one held by the lane 32 positions away (the other half-wave) with ONE
 // v_permlane32_swap (VALU, no LDS crossbar): after swapping (x, x) every lane holds {own, other}.
@@ -57,6 +59,14 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) {
 }
 __device__ __forceinline__ void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r.v, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_offset, 0, 0, 0);
+}
+// 16 bytes per lane through a buffer descriptor: a lane whose byte offset (+16) is out of range loads zeros / stores nothing,
+// so row tails and column tails of a tile cost a v_cndmask on the offset instead of a branch around the access
+__device__ __forceinline__ u32x4 buf_load16(const BufRsrc& r, unsigned byte_offset) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.v, byte_offset, 0, 0));
+}
+__device__ __forceinline__ void buf_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r.v, byte_offset, 0, 0);
 }
 // Transposing LDS read (ds_read_b64_tr_b16): every lane passes the address of 4 consecutive 16-bit elements; inside
 // each 16-lane group, lane l = 4a + b receives element b of lanes a, 4 + a, 8 + a, 12 + a.  With lane s pointing at
@@ -140,6 +150,24 @@ __device__ __forceinline__ void acc_zero(AccFile& af) {
     } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) af.v[B - 16][e] = 0.0f;
+        asm volatile("s_nop 4" : "+v"(af.v[B - 16]));
+    }
+}
+// block B = v (the lane's 16 columns of the bias: the accumulation starts from it, the epilogue adds nothing)
+template <int B>
+__device__ __forceinline__ void acc_init(AccFile& af, const f32x16& v) {
+    if constexpr (B < 16) {
+#define AA_X(b, ...) if constexpr (B == b) asm volatile( \
+            "v_accvgpr_write_b32 a[%c0+0], %1\n\tv_accvgpr_write_b32 a[%c0+1], %2\n\tv_accvgpr_write_b32 a[%c0+2], %3\n\tv_accvgpr_write_b32 a[%c0+3], %4\n\t" \
+            "v_accvgpr_write_b32 a[%c0+4], %5\n\tv_accvgpr_write_b32 a[%c0+5], %6\n\tv_accvgpr_write_b32 a[%c0+6], %7\n\tv_accvgpr_write_b32 a[%c0+7], %8\n\t" \
+            "v_accvgpr_write_b32 a[%c0+8], %9\n\tv_accvgpr_write_b32 a[%c0+9], %10\n\tv_accvgpr_write_b32 a[%c0+10], %11\n\tv_accvgpr_write_b32 a[%c0+11], %12\n\t" \
+            "v_accvgpr_write_b32 a[%c0+12], %13\n\tv_accvgpr_write_b32 a[%c0+13], %14\n\tv_accvgpr_write_b32 a[%c0+14], %15\n\tv_accvgpr_write_b32 a[%c0+15], %16\n\t" \
+            "s_nop 4" ::"i"(16 * b), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), \
+                        "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]) : __VA_ARGS__);
+        AA_ACC_LITERAL_BLOCKS(AA_X)
+#undef AA_X
+    } else {
+        af.v[B - 16] = v;
         asm volatile("s_nop 4" : "+v"(af.v[B - 16]));
     }
 }

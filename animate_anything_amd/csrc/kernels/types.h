@@ -10,6 +10,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));     // packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte global/LDS transaction
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 

@@ -184,6 +184,8 @@ inline float wave_shfl(float v, int src) {
 }
 
 inline float fast_exp2(float x) { return std::exp2(x); }
+inline float fast_rcp(float x) { return 1.0f / x; }
+inline float clamp_f(float x, float lo, float hi) { return std::fmin(std::fmax(x, lo), hi); }
 inline float wave_max_halves(float x) { return std::fmax(x, wave_shfl_xor(x, 32)); }
 inline float wave_sum_halves(float x) { return x + wave_shfl_xor(x, 32); }
 
@@ -230,6 +232,14 @@ inline void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_w
     if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(dst, r.base + byte_offset, 16);
     else std::memset(dst, 0, 16);
 }
+inline u32x4 buf_load16(const BufRsrc& r, unsigned byte_offset) {
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(&v, r.base + byte_offset, 16);
+    return v;
+}
+inline void buf_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
+    if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(const_cast<char*>(r.base) + byte_offset, &v, 16);
+}
 inline int wave_id() { return emu::linear_tid() >> 6; }
 inline u32x2 lds_read_tr16_b64(const void* lds_ptr) {
     unsigned short r[4] = {0, 0, 0, 0};
@@ -263,6 +273,7 @@ inline float fabsf_(float x) { return std::fabs(x); }
 constexpr int ACC_BLOCKS = 20;
 struct AccFile { f32x16 blk[ACC_BLOCKS]; };
 template <int B> inline void acc_zero(AccFile& af) { for (int e = 0; e < 16; ++e) af.blk[B][e] = 0.0f; }
+template <int B> inline void acc_init(AccFile& af, const f32x16& v) { af.blk[B] = v; }
 template <int B> inline void acc_mfma(AccFile& af, f16_t, const u32x4& w, const u32x4& a) { af.blk[B] = emu_mfma_32x32x16<f16_t>(w, a, af.blk[B]); }
 template <int B> inline void acc_mfma(AccFile& af, bf16_t, const u32x4& w, const u32x4& a) { af.blk[B] = emu_mfma_32x32x16<bf16_t>(w, a, af.blk[B]); }
 inline void acc_settle() {}
