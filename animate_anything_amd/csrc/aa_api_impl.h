@@ -93,6 +93,10 @@ static const CgCfg kCgCfgs[] = {
     // two 4-wave workgroups per CU (64x128 per wave, a[0:127]), three-slot ring: one multiplies while the other is in its epilogue
     {128, 256, 2, 2, 32, 3, 2, 1.20f, 0, 1}, // 44
     {256, 128, 4, 1, 32, 3, 2, 1.20f, 0, 1}, // 45
+    // the shapes the 34 x 16 x 16 and 34 x 8 x 8 levels (8704 / 2176 rows) fill the chip with
+    {192, 256, 2, 2, 64, 2, 1, 1.30f, 0, 1}, // 46 one wave per SIMD, 96x128 per wave (a[0:191])
+    {128, 128, 2, 2, 64, 2, 2, 1.00f, 0, 1}, // 47 two 4-wave workgroups per CU, 64x64 per wave (a[0:63])
+    {128, 128, 2, 2, 32, 4, 2, 1.00f, 0, 1}, // 48 the same on the deep ring
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -281,6 +285,9 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 43: cg_launch_x<T, 256, 256, 4, 2, 32, 2, 0, 0>(d, m_begin, m_end, splits, stream); break;
         case 44: cg_launch_x<T, 128, 256, 2, 2, 32, 3, 0, 0, 3, 2>(d, m_begin, m_end, splits, stream); break;
         case 45: cg_launch_x<T, 256, 128, 4, 1, 32, 3, 0, 0, 3, 2>(d, m_begin, m_end, splits, stream); break;
+        case 46: cg_launch_x<T, 192, 256, 2, 2, 64, 5, 5, 4>(d, m_begin, m_end, splits, stream); break;
+        case 47: cg_launch_x<T, 128, 128, 2, 2, 64, 2, 2, 2, 2, 2>(d, m_begin, m_end, splits, stream); break;
+        case 48: cg_launch_x<T, 128, 128, 2, 2, 32, 2, 0, 0, 4, 2>(d, m_begin, m_end, splits, stream); break;
         default: return false;
     }
     return true;

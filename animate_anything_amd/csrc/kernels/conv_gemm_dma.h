@@ -66,25 +66,33 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
             const int nc = (GEGLU ? (n_wave >> 1) : n_wave) + h * 32 + 16 * eh + 8 * q;
             coff[h][q] = nc + 8 <= n_cols ? (unsigned)nc * 2u : OOB;
         }
-    static_for<MI>([&](auto i_) __attribute__((always_inline)) {
+    // the row vector (else the residual) of a whole block row is fetched one block row AHEAD: a wave that is alone on its SIMD
+    // has nothing else to run while a load is in flight
+    u32x4 pre[2][NJ][2];
+    auto prefetch = [&](auto i_) __attribute__((always_inline)) {
         constexpr int i = decltype(i_)::value;
         const unsigned row = (unsigned)(i * 32 + ec);
-        const unsigned o_row = row * (unsigned)p.ldo * 2u;
-        u32x4 pre[NJ][2];                                  // the row vector (else the residual) of the whole block row, fetched up front
         if constexpr (RV) {
             const int mc = min(m_wave + (int)row, M - 1);
             const unsigned rv_row = (unsigned)((mc / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out)) * 2u;
 #pragma unroll
             for (int h = 0; h < NJ; ++h)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) pre[h][q] = buf_load16(r_rv, rv_row + coff[h][q]);
+                for (int q = 0; q < 2; ++q) pre[i & 1][h][q] = buf_load16(r_rv, rv_row + coff[h][q]);
         } else if constexpr (POST) {
             const unsigned r_row = row * (unsigned)p.ldr * 2u;
 #pragma unroll
             for (int h = 0; h < NJ; ++h)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) pre[h][q] = buf_load16(r_res, r_row + coff[h][q]);
+                for (int q = 0; q < 2; ++q) pre[i & 1][h][q] = buf_load16(r_res, r_row + coff[h][q]);
         }
+    };
+    prefetch(IntTag<0>());
+    static_for<MI>([&](auto i_) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_)::value;
+        const unsigned row = (unsigned)(i * 32 + ec);
+        const unsigned o_row = row * (unsigned)p.ldo * 2u;
+        if constexpr (i + 1 < MI) prefetch(IntTag<i + 1>());
         static_for<NJ>([&](auto h_) __attribute__((always_inline)) {
             constexpr int h = decltype(h_)::value, j = GEGLU ? 2 * h : h;
             float v[16];
@@ -104,7 +112,7 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
             if constexpr (RV) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    Pack8<T> r; r.raw = pre[h][q];
+                    Pack8<T> r; r.raw = pre[i & 1][h][q];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[8 * q + e] += (float)r.e[e];
                 }
@@ -134,7 +142,7 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     Pack8<T> r;
-                    if constexpr (RV) r.raw = buf_load16(r_res, row * (unsigned)p.ldr * 2u + coff[h][q]); else r.raw = pre[h][q];
+                    if constexpr (RV) r.raw = buf_load16(r_res, row * (unsigned)p.ldr * 2u + coff[h][q]); else r.raw = pre[i & 1][h][q];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[8 * q + e] = (v[8 * q + e] * acc_scale + (float)r.e[e]) * out_scale;
                 }

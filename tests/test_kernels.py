@@ -313,7 +313,7 @@ def test_geglu_dma_path_wide(backend):
     close(y, (h[:, :D] * F.gelu(h[:, D:])).half().float() + r.float())
 
 
-@pytest.mark.parametrize("cfg,N", [(0, 320), (1, 640), (2, 256), (3, 256), (4, 640), (5, 320), (6, 320), (7, 512), (8, 128), (9, 64), (10, 640), (11, 320), (12, 256), (13, 512), (14, 320), (15, 256), (16, 128), (17, 64), (18, 128), (19, 64), (20, 256), (21, 320), (22, 256), (23, 256), (24, 256), (25, 256), (26, 320), (27, 256), (28, 256), (29, 640), (30, 320), (31, 128), (32, 320), (33, 256), (36, 256), (37, 640), (38, 512), (39, 320), (40, 256), (41, 256), (42, 640), (43, 512), (44, 256), (45, 128)])
+@pytest.mark.parametrize("cfg,N", [(0, 320), (1, 640), (2, 256), (3, 256), (4, 640), (5, 320), (6, 320), (7, 512), (8, 128), (9, 64), (10, 640), (11, 320), (12, 256), (13, 512), (14, 320), (15, 256), (16, 128), (17, 64), (18, 128), (19, 64), (20, 256), (21, 320), (22, 256), (23, 256), (24, 256), (25, 256), (26, 320), (27, 256), (28, 256), (29, 640), (30, 320), (31, 128), (32, 320), (33, 256), (36, 256), (37, 640), (38, 512), (39, 320), (40, 256), (41, 256), (42, 640), (43, 512), (44, 256), (45, 128), (46, 256), (47, 128), (48, 128)])
 def test_dma_tile_shapes(backend, cfg, N):
     """Every tile shape of the LDS-DMA kernel (forced), conv3x3 with halo + M tail + residual."""
     from animate_anything_amd import _lib
@@ -341,7 +341,7 @@ def test_geglu_wide_tiles(backend, D):
     close(ops.conv_gemm(x, pw, ops.linear_geom(M)), h[:, :D] * F.gelu(h[:, D:]))
 
 
-@pytest.mark.parametrize("cfg,splits", [(1, 3), (3, 5), (16, 2), (36, 5), (39, 3), (40, 2), (41, 5), (42, 3), (43, 4), (41, 7), (44, 5), (45, 4)])
+@pytest.mark.parametrize("cfg,splits", [(1, 3), (3, 5), (16, 2), (36, 5), (39, 3), (40, 2), (41, 5), (42, 3), (43, 4), (41, 7), (44, 5), (45, 4), (46, 3), (47, 4), (48, 5)])
 def test_explicit_k_splits(backend, cfg, splits):
     """Caller-chosen K split count (autotuner): uneven K ranges, fp32 partials, reduce launch with the fused epilogue."""
     from animate_anything_amd import _lib
@@ -361,7 +361,7 @@ def test_explicit_k_splits(backend, cfg, splits):
     close(y, ref)
 
 
-@pytest.mark.parametrize("cfg", [23, 25, 3, 36, 38, 40, 41, 43, 44, 45])
+@pytest.mark.parametrize("cfg", [23, 25, 3, 36, 38, 40, 41, 43, 44, 45, 46, 47, 48])
 def test_geglu_forced_tiles(backend, cfg):
     """GEGLU value/gate pairing inside one wavefront for the 4-wave-column tiles (NI = 2) and the 2-column ones (NI = 4)."""
     from animate_anything_amd import _lib
@@ -561,7 +561,7 @@ def test_halo_slab_eligibility(emu):
     assert lib.aa_conv_gemm_tile_ok(C.byref(d), 34) == 0 and lib.aa_conv_gemm_tile_ok(C.byref(d), 14) == 1
 
 
-X_TILES = [(36, 256), (37, 320), (38, 256), (39, 320), (40, 256), (41, 256), (42, 320), (43, 256), (44, 256), (45, 128)]
+X_TILES = [(36, 256), (37, 320), (38, 256), (39, 320), (40, 256), (41, 256), (42, 320), (43, 256), (44, 256), (45, 128), (46, 256), (47, 128), (48, 128)]
 
 
 @pytest.mark.parametrize("cfg,N", X_TILES)
@@ -620,7 +620,7 @@ def test_x_tiles_are_not_offered_behind_a_resize(emu):
     assert lib.aa_conv_gemm_tile_ok(C.byref(d), 37) == 0 and lib.aa_conv_gemm_tile_ok(C.byref(d), 14) == 1
 
 
-@pytest.mark.parametrize("cfg,N", [(41, 256), (42, 320), (43, 256), (36, 256), (44, 256), (45, 128)])
+@pytest.mark.parametrize("cfg,N", [(41, 256), (42, 320), (43, 256), (36, 256), (44, 256), (45, 128), (46, 256), (48, 128)])
 @pytest.mark.parametrize("K,splits", [(128, 4), (192, 2), (320, 2), (448, 2)])
 def test_x_tiles_short_and_odd_k_ranges(backend, cfg, N, K, splits):
     """K ranges of 1, 3, 5 and 7 stages of 32 (split K): the deep ring's prologue and every peeled tail step."""
