@@ -106,7 +106,7 @@ class AaEulerStepTok(C.Structure):
     ]
 
 
-SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_groupnorm_workspace", "aa_groupnorm",
+SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_groupnorm_workspace", "aa_groupnorm", "aa_set_groupnorm_two_pass", "aa_groupnorm_plan",
            "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step",
            "aa_timestep_embedding", "aa_pack_latents", "aa_cfg_dpm_step_tokens",
            "aa_blend", "aa_pack_frames", "aa_cfg_euler_step_tokens")
@@ -133,6 +133,10 @@ def bind(path: str) -> C.CDLL:
     lib.aa_conv_gemm_tile_ok.restype = C.c_int
     lib.aa_conv_gemm.argtypes = [C.POINTER(AaConvGemm), C.c_void_p]
     lib.aa_conv_gemm_launch_count.argtypes = [C.POINTER(AaConvGemm)]
+    lib.aa_set_groupnorm_two_pass.argtypes = [C.c_int]
+    lib.aa_set_groupnorm_two_pass.restype = None
+    lib.aa_groupnorm_plan.argtypes = [C.POINTER(AaGroupNorm), C.POINTER(C.c_int32)]
+    lib.aa_groupnorm_plan.restype = C.c_int
     lib.aa_conv_gemm_workspace.argtypes = [C.POINTER(AaConvGemm)]
     lib.aa_conv_gemm_workspace.restype = C.c_size_t
     lib.aa_groupnorm_workspace.argtypes = [C.POINTER(AaGroupNorm)]

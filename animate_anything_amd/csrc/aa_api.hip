@@ -37,4 +37,5 @@ static const char* aa_post_launch() {
 }
 #define AA_POST_LAUNCH() aa_post_launch()
 
+
 #include "aa_api_impl.h"

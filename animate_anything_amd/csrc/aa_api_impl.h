@@ -343,6 +343,54 @@ static int groupnorm_t(const AaGroupNorm& d, float* ws, int chunks, int apply_ch
     return finish("groupnorm");
 }
 
+// ---- single-pass GroupNorm (norm.h: groupnorm_fused_kernel): which channel block / rows per thread, if one workgroup can
+// hold every token of an image group at all.  Whether it beats the two-kernel pair is the caller's measurement (ops.py).
+struct GnfPlan { int gb, nr, parts, grid; };
+static bool gnf_plan(const AaGroupNorm& d, GnfPlan& best) {
+    const int C = d.c0 + d.c1, G = d.num_groups, cg = C / G;
+    static const int kNR[] = {8, 16, 24, 32, 48};
+    bool found = false;
+    long best_est = 0;
+    for (int gb = 1; gb <= G; gb *= 2) {
+        if (G % gb || (gb * cg) % 8 || (gb * cg) / 8 > GNF_THREADS) continue;
+        const int cw = gb * cg, sw = cw / 8, rpp = GNF_THREADS / sw;
+        if (rpp * sw * 4 < GNF_THREADS * 3) continue;                      // more than a quarter of the threads idle
+        if (gnf_lds_bytes(cw, gb) > 64 * 1024) continue;
+        for (int k = 0; k < 5; ++k) {
+            const int nr = kNR[k], pt = rpp * nr;
+            if (pt < d.tokens_per_group) continue;                         // one workgroup per (image group, channel block)
+            const long grid = (long)d.n_groups_img * (G / gb);
+            if (grid > 65535L * 16) break;
+            // estimated time (ns; calibrated on the r03q measurements): a workgroup needs a fixed ~8 us (launch share, two memory
+            // round trips, the reductions) plus its bytes at ~25 GB/s; a grid beyond what is resident at once runs in rounds;
+            // row segments below 160 bytes waste DRAM bursts
+            const long resident = (nr <= 16 ? 2 : 1) * 256L;              // launch bounds: 4 (2) waves per SIMD = 2 (1) workgroups per CU
+            const long rounds = (grid + resident - 1) / resident;
+            long est = rounds * (8000 + (long)d.tokens_per_group * cw * 4 / 25);
+            if (cw * 2 < 160) est = est * 160 / (cw * 2);
+            if (grid < 128) est += (128 - grid) * 100;                      // too few workgroups to pull the HBM rate
+            if (!found || est < best_est) { best_est = est; best = GnfPlan{gb, nr, 1, (int)grid}; found = true; }
+            break;                                                          // (a larger nr only costs registers)
+        }
+    }
+    return found;
+}
+
+template <typename T>
+static void gnf_launch(const AaGroupNorm& d, const GnfPlan& pl, void* stream) {
+    const int cw = pl.gb * ((d.c0 + d.c1) / d.num_groups);
+    const dim3 grid(1, d.num_groups / pl.gb, d.n_groups_img), block(GNF_THREADS);
+    const size_t lds = gnf_lds_bytes(cw, pl.gb);
+    switch (pl.nr) {
+        case 8:  AA_LAUNCH((groupnorm_fused_kernel<T, 8>), grid, block, lds, stream, d, pl.gb); break;
+        case 16: AA_LAUNCH((groupnorm_fused_kernel<T, 16>), grid, block, lds, stream, d, pl.gb); break;
+        case 24: AA_LAUNCH((groupnorm_fused_kernel<T, 24>), grid, block, lds, stream, d, pl.gb); break;
+        case 32: AA_LAUNCH((groupnorm_fused_kernel<T, 32>), grid, block, lds, stream, d, pl.gb); break;
+        default: AA_LAUNCH((groupnorm_fused_kernel<T, 48>), grid, block, lds, stream, d, pl.gb); break;
+    }
+}
+
+static thread_local bool g_gn_two_pass = false;      // aa_set_groupnorm_two_pass(1): the statistics + apply kernel pair (tests, A/B timing)
 static int gn_chunks(const AaGroupNorm& d) {
     // aim for >= ~1024 workgroups, at least 16 tokens each, at most 256 chunks per image group (every apply workgroup
     // re-reduces its image group's chunk partials: measured 54 us at 256 chunks vs 94 us at 1024 for the clip-wide
@@ -449,6 +497,14 @@ size_t aa_groupnorm_workspace(const AaGroupNorm* d) {
     return (size_t)d->n_groups_img * aa::gn_chunks(*d) * d->num_groups * 2 * sizeof(float);
 }
 
+void aa_set_groupnorm_two_pass(int on) { aa::g_gn_two_pass = on != 0; }
+int aa_groupnorm_plan(const AaGroupNorm* d, int32_t info[4]) {
+    aa::GnfPlan pl;
+    if (!d || !info || aa::g_gn_two_pass || !aa::gnf_plan(*d, pl)) return 0;
+    info[0] = pl.gb; info[1] = pl.nr; info[2] = pl.parts; info[3] = pl.grid;
+    return 1;
+}
+
 int aa_groupnorm(const AaGroupNorm* d, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace aa;
     if (!d) return fail(AA_E_SHAPE, "groupnorm: null descriptor");
@@ -459,10 +515,16 @@ int aa_groupnorm(const AaGroupNorm* d, void* workspace, size_t workspace_bytes, 
     if (!aligned16(d->x0) || !aligned16(d->x1) || !aligned16(d->y)) return fail(AA_E_ALIGN, "groupnorm: operands must be 16-byte aligned");
     const size_t need = aa_groupnorm_workspace(d);
     if (!workspace || workspace_bytes < need) return fail(AA_E_WORKSPACE, "groupnorm: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (d->dtype != AA_F16 && d->dtype != AA_BF16) return fail(AA_E_DTYPE, "groupnorm: unsupported dtype %d", d->dtype);
+    GnfPlan pl;
+    if (!g_gn_two_pass && gnf_plan(*d, pl)) {
+        if (d->dtype == AA_F16) gnf_launch<f16_t>(*d, pl, stream);
+        else gnf_launch<bf16_t>(*d, pl, stream);
+        return finish("groupnorm");
+    }
     const int chunks = gn_chunks(*d);
     if (d->dtype == AA_F16) return groupnorm_t<f16_t>(*d, (float*)workspace, chunks, chunks, stream);
-    if (d->dtype == AA_BF16) return groupnorm_t<bf16_t>(*d, (float*)workspace, chunks, chunks, stream);
-    return fail(AA_E_DTYPE, "groupnorm: unsupported dtype %d", d->dtype);
+    return groupnorm_t<bf16_t>(*d, (float*)workspace, chunks, chunks, stream);
 }
 
 int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t channels,

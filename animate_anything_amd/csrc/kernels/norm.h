@@ -219,6 +219,123 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_apply_kernel(const AaGro
     }
 }
 
+// ---- GroupNorm in ONE pass over HBM: a workgroup owns `GB` channel groups (CW = GB * C/num_groups channels: a row segment of
+// CW * 2 bytes) of ALL tokens of one image group (at most rpp * NR) and keeps them in REGISTERS (NR 16-byte pieces per
+// thread; a CU's register file holds 512 KB) between the statistics and the normalisation: x is read once and y written
+// once, one launch instead of two.
+// Only where ONE workgroup can hold every token of its image group (the per-frame norms of the 16x16 / 8x8 levels, some of the
+// 32x32 ones): the statistics are then complete inside the workgroup.  (Measured and dropped, r03q: several workgroups per
+// image group meeting at a global counter - clip-wide norms, the 64x64 level - cost 30+ us per rendezvous across the XCDs:
+// 2-3x slower than the two-kernel pair.)
+// grid = (1, num_groups / GB, n_groups_img).  Statistics centred on the group's first element, as above.
+constexpr int GNF_THREADS = 512;
+__host__ __device__ inline int gnf_lds_bytes(int cw, int gb) { return (GNF_THREADS / (cw / 8)) * 2 * cw * 4 + 4 * cw * 4 + 4 * gb * 4; }
+
+template <typename T, int NR>
+__global__ void __launch_bounds__(GNF_THREADS, NR <= 16 ? 4 : 2) groupnorm_fused_kernel(const AaGroupNorm p, const int GB) {
+    const int C = p.c0 + p.c1, cg = C / p.num_groups;
+    const int CW = GB * cg, SW = CW >> 3, rpp = GNF_THREADS / SW;
+    const int tid = threadIdx.x;
+    const int slot = tid % SW, roff = tid / SW;
+    const bool active = roff < rpp;
+    const int gb = blockIdx.y, ig = blockIdx.z;
+    const int64_t base = (int64_t)ig * p.tokens_per_group;
+    const int cbase = gb * CW + slot * 8;
+    const T* x0 = reinterpret_cast<const T*>(p.x0);
+    const T* x1 = reinterpret_cast<const T*>(p.x1);
+    float* s_part = reinterpret_cast<float*>(dyn_smem());        // [rpp][2][CW]
+    float* s_csum = s_part + rpp * 2 * CW;                        // [2][CW]
+    float* s_scale = s_csum + 2 * CW;                             // [CW]
+    float* s_shift = s_scale + CW;                                // [CW]
+    float* s_stat = s_shift + CW;                                 // [GB][2] sums, then mean / rstd
+
+    Pack8<T> v[NR];
+    float a[8], b[8], kp[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 0.0f; b[e] = 0.0f; kp[e] = 0.0f; }
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kp[e] = gn_pivot<T>(x0, x1, p.c0, p.c1, base, ((cbase + e) / cg) * cg);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {                            // every piece of this thread is in flight before the first use
+            const int t = roff + r * rpp;
+            v[r].raw = u32x4{0u, 0u, 0u, 0u};
+            if (t < p.tokens_per_group) v[r].raw = load8<T>(x0, x1, p.c0, p.c1, base + t, cbase);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int t = roff + r * rpp;
+            if (t < p.tokens_per_group) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[r].e[e] - kp[e]; a[e] += f; b[e] += f * f; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s_part[(roff * 2 + 0) * CW + slot * 8 + e] = a[e];
+            s_part[(roff * 2 + 1) * CW + slot * 8 + e] = b[e];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * CW; c += GNF_THREADS) {            // fixed summation order: bit-reproducible
+        const int which = c / CW, cc = c - which * CW;
+        float acc = 0.0f;
+        for (int rr = 0; rr < rpp; ++rr) acc += s_part[(rr * 2 + which) * CW + cc];
+        s_csum[c] = acc;
+    }
+    __syncthreads();
+    if (tid < GB) {
+        float sa = 0.0f, sb = 0.0f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) { sa += s_csum[c]; sb += s_csum[CW + c]; }
+        s_stat[2 * tid] = sa; s_stat[2 * tid + 1] = sb;
+    }
+    __syncthreads();
+    if (tid < GB) {
+        const float cnt = (float)p.tokens_per_group * (float)cg;
+        const float dm = s_stat[2 * tid] / cnt;
+        const float var = fmaxf(s_stat[2 * tid + 1] / cnt - dm * dm, 0.0f);
+        const float mean = dm + gn_pivot<T>(x0, x1, p.c0, p.c1, base, (gb * GB + tid) * cg);
+        s_stat[2 * GB + 2 * tid] = mean;
+        s_stat[2 * GB + 2 * tid + 1] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    {
+        const T* gamma = reinterpret_cast<const T*>(p.gamma);
+        const T* beta = reinterpret_cast<const T*>(p.beta);
+        for (int c = tid; c < CW; c += GNF_THREADS) {
+            const int g = c / cg;
+            const float mean = s_stat[2 * GB + 2 * g], rstd = s_stat[2 * GB + 2 * g + 1];
+            const float sc = rstd * (float)gamma[gb * CW + c];
+            s_scale[c] = sc;
+            s_shift[c] = (float)beta[gb * CW + c] - mean * sc;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = s_scale[slot * 8 + e]; sh[e] = s_shift[slot * 8 + e]; }
+    const bool silu = p.silu != 0;
+    T* y = reinterpret_cast<T*>(p.y);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int t = roff + r * rpp;
+        if (t < p.tokens_per_group) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)v[r].e[e] * sc[e] + sh[e];
+            if (silu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] / (1.0f + __expf(-f[e]));
+            }
+            Pack8<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = (T)f[e];
+            *reinterpret_cast<u32x4*>(y + (base + t) * C + cbase) = o.raw;
+        }
+    }
+}
+
 // ---- LayerNorm: a wavefront owns LN_ROWS<SJ> rows at a time, the rows live in registers (C <= 2048), two-pass variance.
 // SJ = 16-byte slots per lane and row (C <= 512 * SJ); narrow rows are processed several at once so that every wave
 // keeps four independent 16-byte loads in flight (a 640-byte row per wave leaves HBM latency exposed).

@@ -29,6 +29,7 @@ TRACE = None
 # operands and the fastest index is remembered for that signature (descriptor field `tile`).
 AUTOTUNE = True
 LAST_STAMPS = None
+GN_PLANS = None            # a list: groupnorm() appends (groups per workgroup, pieces per thread, parts, grid) or None per call
 MAX_OPERAND_BYTES = 1 << 31      # the contraction kernel's 32-bit operand offsets
 K_SPLITS = 0          # tests: explicit K split count for calls that are not autotuned (0 = library decides)
 DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
@@ -181,6 +182,37 @@ def _autotune(lib, d, stream, key, rows, dev):
         if final:
             best = final[0][1]
         d.workspace, d.workspace_bytes = ws_keep
+    _tile_cache[key] = best
+    return best
+
+
+def _autotune_groupnorm(lib, d, ws, nbytes, stream, key):
+    """(1, 0) if the statistics + apply pair beats the single kernel for this signature, else (0, 0)."""
+    global AUTOTUNE_EVENTS
+    info = (C.c_int32 * 4)()
+    best = (0, 0)
+    if lib.aa_groupnorm_plan(C.byref(d), info):
+        AUTOTUNE_EVENTS += 1
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def timed(two):
+            lib.aa_set_groupnorm_two_pass(two)
+            try:
+                ts = []
+                for i in range(9):
+                    e0.record()
+                    lib.aa_groupnorm(C.byref(d), C.c_void_p(ws.data_ptr()), nbytes, stream)
+                    e1.record()
+                    e1.synchronize()
+                    if i >= 2:
+                        ts.append(e0.elapsed_time(e1))
+            finally:
+                lib.aa_set_groupnorm_two_pass(0)
+            ts.sort()
+            return ts[len(ts) // 2]
+
+        t1, t2 = timed(0), timed(1)
+        best = (1, 0) if t2 < t1 else (0, 0)
     _tile_cache[key] = best
     return best
 
@@ -429,7 +461,27 @@ def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_group
     d.silu, d.dtype, d.eps = int(silu), _DT[x0.dtype], eps
     nbytes = lib.aa_groupnorm_workspace(C.byref(d))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x0.device)
-    _run(lib.aa_groupnorm, C.byref(d), _ptr(ws), nbytes, _stream(x0))
+    # one kernel (x kept in registers between statistics and normalisation) or the statistics + apply pair: the library offers
+    # the single kernel wherever the shape allows; which of the two is faster is measured once per signature and kept with
+    # the tile choices (key (-1, ...): tile_cache_gfx950.json)
+    two_pass = False
+    if AUTOTUNE and x0.is_cuda:
+        key = (-1, d.dtype, c0, c1, n_groups_img, tokens_per_group, num_groups, int(silu))
+        _load_default_tile_cache()
+        choice = _tile_cache.get(key)
+        if choice is None and y.data_ptr() != x0.data_ptr() and not torch.cuda.is_current_stream_capturing():
+            choice = _autotune_groupnorm(lib, d, ws, nbytes, _stream(x0), key)
+        two_pass = bool(choice and choice[0])
+    if two_pass:
+        lib.aa_set_groupnorm_two_pass(1)
+    try:
+        if GN_PLANS is not None:                          # (tests / bench breakdown) how this call runs: None = two kernels
+            info = (C.c_int32 * 4)()
+            GN_PLANS.append(tuple(info) if lib.aa_groupnorm_plan(C.byref(d), info) else None)
+        _run(lib.aa_groupnorm, C.byref(d), _ptr(ws), nbytes, _stream(x0))
+    finally:
+        if two_pass:
+            lib.aa_set_groupnorm_two_pass(0)
     return y
 
 

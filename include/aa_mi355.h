@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AA_VERSION 103
+#define AA_VERSION 104
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
@@ -146,6 +146,12 @@ typedef struct AaGroupNorm {
 } AaGroupNorm;
 
 size_t aa_groupnorm_workspace(const AaGroupNorm* d);
+/* 1: always the two-kernel form (statistics, then normalise); 0 (default): one kernel that keeps x in registers between the
+ * two wherever the shape allows.  Per calling thread; for tests and A/B timing. */
+void aa_set_groupnorm_two_pass(int on);
+/* 1 and info = {channel groups per workgroup, 16-byte pieces per thread, workgroups per (image group, channel block), grid size}
+ * if this call runs as one kernel, 0 if it runs as the statistics + normalise pair. */
+int aa_groupnorm_plan(const AaGroupNorm* d, int32_t info[4]);
 int aa_groupnorm(const AaGroupNorm* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* aa_layernorm: nn.LayerNorm(C, eps) over the last dim of [rows][C]

@@ -151,17 +151,26 @@ for c, hw in LEVELS[:3]:
                bytes_=2.0 * N * L * c * 2)
 
 # ------------------------------------------------------------------ norms
-for c, hw in LEVELS[:3] + [(960, 64), (2560, 16)]:
+# bytes: one read + one write of the tensor (what a GroupNorm has to move); each GroupNorm is timed as the single kernel the
+# library picks (plan = groups per workgroup / pieces per thread / workgroups per image group / grid) and as the two-kernel pair
+from animate_anything_amd import _lib as _lib_
+for c, hw in LEVELS[:4] + [(640, 64), (960, 64), (1280, 32), (1920, 32), (2560, 16)]:
     tok = N * hw * hw
-    name = f"groupnorm2d+silu C={c} {hw}x{hw}"
-    if want(name):
+    for kind, ig, tpg in (("2d", N, hw * hw), ("3d", B, T * hw * hw)):
+        name = f"groupnorm{kind}+silu C={c} {hw}x{hw}"
+        if not want(name) or (kind == "3d" and c not in (320, 640, 1280)):
+            continue
         x, gm, bt = rnd(tok, c), rnd(c), rnd(c)
-        report(name, timeit(lambda: ops.groupnorm(x, gm, bt, N, hw * hw, 32, 1e-5, True)), bytes_=3.0 * tok * c * 2)
-    name = f"groupnorm3d+silu C={c} {hw}x{hw}"
-    if want(name) and c in (320, 640, 1280):
-        x, gm, bt = rnd(tok, c), rnd(c), rnd(c)
-        report(name, timeit(lambda: ops.groupnorm(x, gm, bt, B, T * hw * hw, 32, 1e-5, True)), bytes_=3.0 * tok * c * 2)
+        ops.GN_PLANS = []
+        ops.groupnorm(x, gm, bt, ig, tpg, 32, 1e-5, True)
+        plan, ops.GN_PLANS = ops.GN_PLANS[0], None
+        report(f"{name} one kernel {plan}" if plan else f"{name} (two kernels: no one-kernel plan)",
+               timeit(lambda: ops.groupnorm(x, gm, bt, ig, tpg, 32, 1e-5, True)), bytes_=2.0 * tok * c * 2)
+        if plan:
+            _lib_.get().aa_set_groupnorm_two_pass(1)
+            report(f"{name} two kernels", timeit(lambda: ops.groupnorm(x, gm, bt, ig, tpg, 32, 1e-5, True)), bytes_=2.0 * tok * c * 2)
+            _lib_.get().aa_set_groupnorm_two_pass(0)
     name = f"layernorm C={c} {hw}x{hw}"
-    if want(name) and c in (320, 640, 1280):
+    if want(name) and c in (320, 640, 1280) and (c, hw) in LEVELS:
         x, gm, bt = rnd(tok, c), rnd(c), rnd(c)
         report(name, timeit(lambda: ops.layernorm(x, gm, bt)), bytes_=2.0 * tok * c * 2)

@@ -148,6 +148,36 @@ def test_groupnorm_large_mean(backend):
     close(y, ref, tol=5e-3)
 
 
+@pytest.mark.parametrize("C,hw,frames,c1", [(320, 64, 1, 0), (640, 256, 1, 0), (1280, 64, 3, 0), (640, 100, 1, 320), (320, 1024, 1, 0), (96, 50, 2, 0), (2560, 256, 1, 1280)])
+def test_groupnorm_one_pass_equals_two_pass(backend, C, hw, frames, c1):
+    """The single-kernel form (x kept in registers between statistics and normalisation) against the statistics + apply pair on
+    the same input, and both against torch."""
+    from animate_anything_amd import _lib
+    n, groups = 2 * frames, 32
+    c0 = C - c1
+    x = rnd(n, C, hw, 1, seed=141) * 1.5 - 0.7
+    gamma, beta = rnd(C, seed=142), rnd(C, seed=143)
+    tok = nhwc(x)
+    x0, x1 = (tok, None) if c1 == 0 else (tok[:, :c0].contiguous(), tok[:, c0:].contiguous())
+    lib = _lib.get()
+    ops.GN_PLANS = []
+    tune, ops.AUTOTUNE = ops.AUTOTUNE, False              # (on a GPU ops.groupnorm would otherwise time the two forms and pick one)
+    try:
+        y1 = ops.groupnorm(x0, gamma, beta, n // frames, frames * hw, groups, eps=1e-5, silu=True, x1=x1)
+        lib.aa_set_groupnorm_two_pass(1)
+        y2 = ops.groupnorm(x0, gamma, beta, n // frames, frames * hw, groups, eps=1e-5, silu=True, x1=x1)
+    finally:
+        lib.aa_set_groupnorm_two_pass(0)
+        ops.AUTOTUNE = tune
+        plans, ops.GN_PLANS = ops.GN_PLANS, None
+    assert plans[0] is not None and plans[1] is None, plans          # these shapes run as one kernel
+    x5 = x.float().reshape(n // frames, frames, C, hw).permute(0, 2, 1, 3)
+    ref = F.silu(F.group_norm(x5, groups, gamma.float(), beta.float(), 1e-5)).permute(0, 2, 3, 1).reshape(-1, C)
+    close(y1, ref)
+    close(y2, ref)
+    close(y1, y2.float(), tol=2e-3)
+
+
 @pytest.mark.parametrize("C", [64, 320, 640, 1280])
 def test_layernorm(backend, C):
     x, g, b = rnd(11, C, seed=28) * 3 + 1, rnd(C, seed=29), rnd(C, seed=30)
