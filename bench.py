@@ -376,13 +376,34 @@ def run_svd(a, rank, world, device):
     print(json.dumps(out), flush=True)
 
 
+def selftest_library():
+    """AA_BENCH_SELFTEST=1 (tests/test_bench_multirank.py only): the N > 1 CONTROL FLOW of this script - respawn under torchrun,
+    rank / WORLD_SIZE checks, clip ownership and seeds, barriers, the gather inside the timed region, max over ranks, the one
+    JSON line of rank 0 - on CPU ranks over gloo, with the test suite's CPU build of the same kernel sources (tests/emu) and a toy
+    architecture.  The line it prints says "selftest" and is not a measurement; without the variable there is no CPU path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from animate_anything_amd import _lib
+    return _lib.use_library(_lib.bind(build_emu.build()), host_pointers=True)
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         respawn_under_torchrun(a)
+    selftest = os.environ.get("AA_BENCH_SELFTEST") == "1"
+    if selftest:
+        with selftest_library():
+            return bench(a, selftest=True)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    return bench(a)
+
+
+def bench(a, selftest=False):
     from animate_anything_amd import distributed as D
-    rank, world, device = D.init("nccl")
+    rank, world, device = D.init("gloo" if selftest else "nccl")
+    sync = (lambda: None) if selftest else torch.cuda.synchronize
     pinned = D.pin_to_gpu_numa_node(device.index or 0) if world > 1 else None      # ranks stay on their GPU's NUMA node
     if a.workload == "svd":
         return run_svd(a, rank, world, device)
@@ -400,11 +421,29 @@ def main():
     from animate_anything_amd.schedulers import DPMSolverMultistepScheduler
 
     lat = a.size // 8
-    unet = build_unet(dtype, device)
+    if selftest:
+        from util import TINY_UNET
+        from animate_anything_amd.unet3d import UNet3DConditionModel
+        torch.manual_seed(0)
+        unet = UNet3DConditionModel(**TINY_UNET).eval()
+        with torch.no_grad():
+            for p_ in unet.parameters():
+                if p_.abs().max() == 0:
+                    p_.normal_(0.0, 0.02)
+        unet = unet.to(dtype)
+        a.no_graph = a.no_roofline = a.no_cpu_baseline = True
+    else:
+        unet = build_unet(dtype, device)
     pipe = LatentToVideoPipeline(vae=None, unet=unet, scheduler=DPMSolverMultistepScheduler())
     num_clips = world                                                             # weak scaling: one clip per GPU
     mine = D.clip_indices(num_clips, rank, world)                                 # == [rank]
     inp = synthetic_inputs(a.frames, lat, dtype, device, seed=D.clip_seed(1234, mine[0]))
+    if selftest:                                                                  # toy geometry: 2 frames of 5 x 6 latents, 9 text tokens of 64
+        g = torch.Generator().manual_seed(D.clip_seed(1234, mine[0]))
+        r = lambda *sh: torch.randn(*sh, generator=g)
+        m = torch.zeros(1, 1, 1, 5, 6)
+        m[..., 1:4, 2:5] = 1
+        inp = dict(latents=r(1, 4, 2, 5, 6), cond=r(1, 4, 1, 5, 6).to(dtype), mask=m.to(dtype), text=r(1, 9, 64).to(dtype), neg=r(1, 9, 64).to(dtype))
     embeds = torch.cat([inp["neg"], inp["text"]])
     total = a.warmup + a.steps
     pipe.scheduler.set_timesteps(max(total, 2))
@@ -427,7 +466,7 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     with torch.no_grad():
         x = run(ts[: a.warmup], inp["latents"]) if a.warmup else inp["latents"]
@@ -488,6 +527,7 @@ def main():
         "metric": metric, "value": round(value, 4), "unit": "steps/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        **({"selftest": "CPU ranks over gloo on the test suite's CPU build of the kernels, toy architecture: control flow only, NOT a measurement"} if selftest else {}),
         "config": {"workload": f"animate_anything_512_v1.02 UNet3D (1413M params, seeded random init), "
                                f"{a.frames} frames x {a.size}x{a.size}, pipeline bs=1 per GPU (CFG batch 2, 17 frames "
                                f"inside), DPM-Solver++ step, hipGraph={'off' if a.no_graph else 'on'}",
@@ -505,7 +545,7 @@ def main():
         with torch.no_grad():
             run(ts[:1], inp["latents"])
         trace, ops.TRACE = ops.TRACE, None
-        torch.cuda.synchronize()
+        sync()
         out["roofline"] = contraction_roofline(trace, a.gemm_breakdown, flop_step, ms_step)
         if a.workload != "unet3d" or (a.frames, a.size, a.dtype) != (16, 512, "fp16"):      # the committed PMC run is of the default command
             out["roofline"]["traffic"] = out["roofline"]["traffic_bytes_per_step"] = out["roofline"]["traffic_over_algorithmic"] = None
