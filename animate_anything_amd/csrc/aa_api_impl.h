@@ -97,6 +97,9 @@ static const CgCfg kCgCfgs[] = {
     {192, 256, 2, 2, 64, 2, 1, 1.30f, 0, 1}, // 46 one wave per SIMD, 96x128 per wave (a[0:191])
     {128, 128, 2, 2, 64, 2, 2, 1.00f, 0, 1}, // 47 two 4-wave workgroups per CU, 64x64 per wave (a[0:63])
     {128, 128, 2, 2, 32, 4, 2, 1.00f, 0, 1}, // 48 the same on the deep ring
+    // 139264 rows = 725.3 tiles of 192: three rounds of 3/4-size tiles and no leftover launch, against two rounds of 256-row tiles
+    // plus a leftover launch that costs ~0.7 of a round
+    {192, 320, 2, 2, 64, 2, 1, 1.35f, 0, 1}, // 49 one wave per SIMD, 96x160 per wave (a[0:239])
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -288,6 +291,7 @@ static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, 
         case 46: cg_launch_x<T, 192, 256, 2, 2, 64, 5, 5, 4>(d, m_begin, m_end, splits, stream); break;
         case 47: cg_launch_x<T, 128, 128, 2, 2, 64, 2, 2, 2, 2, 2>(d, m_begin, m_end, splits, stream); break;
         case 48: cg_launch_x<T, 128, 128, 2, 2, 32, 2, 0, 0, 4, 2>(d, m_begin, m_end, splits, stream); break;
+        case 49: cg_launch_x<T, 192, 320, 2, 2, 64, 6, 5, 5>(d, m_begin, m_end, splits, stream); break;
         default: return false;
     }
     return true;

@@ -106,7 +106,7 @@ def test_x_kernels_keep_hipcc_out_of_the_accumulators(tmp_path):
         assert vgpr <= 512 // waves_per_simd, (name, vgpr)
         body = "\n".join(bodies[name])
         literal_blocks = agpr // 16
-        assert literal_blocks in (4, 8, 12, 16), (name, agpr)
+        assert literal_blocks in (4, 8, 12, 15, 16), (name, agpr)
         # the accumulators are written by the source only: started from the bias at two sites (K loop prologue, empty K range)
         assert len(re.findall(r"v_accvgpr_write", body)) == 2 * 16 * literal_blocks, name
         # read-out sites (split-K partials, the general epilogue, its branch-free forms) read every block exactly once each
