@@ -119,7 +119,15 @@ static bool cg_slab_ok(const AaConvGemm& d, const CgCfg& c) {
 
 // The hand-scheduled tiles (conv_gemm_x.h) do not carry the nearest-neighbour resize of Upsample2D.
 static thread_local unsigned g_x_disabled = 0;   // bit i: table entry 36 + i is not offered (aa_set_tile_override(-100 - mask): bisecting aid)
-static bool cg_x_ok(const AaConvGemm& d) { return d.h_virt == d.h_in && d.w_virt == d.w_in; }
+static bool cg_x_ok(const AaConvGemm& d) {
+    if (!(d.h_virt == d.h_in && d.w_virt == d.w_in)) return false;
+    if (d.rowvec) {          // their epilogue reads the row vector through a buffer descriptor: 32-bit byte offsets below 2^31
+        const int64_t M = (int64_t)d.n_img * d.h_out * d.w_out;
+        const int64_t ld = d.rowvec_ld ? d.rowvec_ld : d.n_out;
+        if (((M - 1) / (d.rowvec_div > 0 ? d.rowvec_div : 1) + 1) * ld * 2 >= ((int64_t)1 << 31)) return false;
+    }
+    return true;
+}
 
 static int cg_choose(const AaConvGemm& d, int M) {
     int best = -1;
@@ -209,9 +217,10 @@ static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) 
         p.workspace = (size_t)ts * (M - p.m_main) * d.n_pad * 4;
         return p;
     }
-    const int small[2] = {1, 0};
-    for (int k = 0; k < 2 && p.tail_cfg < 0; ++k) {
+    const int small[3] = {47, 1, 0};                       // 128x128 (hand-scheduled, then compiled), 128x64
+    for (int k = 0; k < 3 && p.tail_cfg < 0; ++k) {
         const CgCfg& t = kCgCfgs[small[k]];
+        if (t.x && (!cg_x_ok(d) || ((g_x_disabled >> (small[k] - 36)) & 1u))) continue;
         if (d.n_pad % t.bn == 0 && (!d.geglu || (t.bn / t.wn) % 64 == 0)) p.tail_cfg = small[k];
     }
     if (p.tail_cfg < 0) p.tail_cfg = p.cfg;               // no small tile fits (wide GEGLU): big tile again
