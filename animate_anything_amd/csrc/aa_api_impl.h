@@ -430,7 +430,13 @@ static int attention_t(const AaAttention& d, void* stream) {
         AA_LAUNCH((attention_kernel<T, 4>), grid, dim3(256), attn_lds_bytes(d.kv_len), stream, d);
     } else {
         const dim3 grid((d.q_len + 31) / 32, d.heads, nseq);
-        if (d.kv_len <= 32) AA_LAUNCH((attention_kernel<T, 1, 32>), grid, dim3(64), AT_TILE_BYTES / 2, stream, d);
+        if (d.kv_len <= 32 && d.q_len <= 32 && nseq >= 4096) {          // many short sequences: eight (four) per workgroup, one per wave
+            const dim3 grid8(1, d.heads, (nseq + 7) / 8);              // (measured, 64x64 level: 109 -> 93.5 -> 89.0 us; 32x32 level: 45 -> 37.6 / 40.1 us)
+            AA_LAUNCH((attention_kernel<T, 1, 32, 8>), grid8, dim3(512), 8 * (AT_TILE_BYTES / 2), stream, d);
+        } else if (d.kv_len <= 32 && d.q_len <= 32 && nseq >= 256) {
+            const dim3 grid4(1, d.heads, (nseq + 3) / 4);
+            AA_LAUNCH((attention_kernel<T, 1, 32, 4>), grid4, dim3(256), 4 * (AT_TILE_BYTES / 2), stream, d);
+        } else if (d.kv_len <= 32) AA_LAUNCH((attention_kernel<T, 1, 32>), grid, dim3(64), AT_TILE_BYTES / 2, stream, d);
         else                AA_LAUNCH((attention_kernel<T, 1>), grid, dim3(64), attn_lds_bytes(d.kv_len), stream, d);
     }
     return finish("attention");

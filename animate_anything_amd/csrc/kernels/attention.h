@@ -55,20 +55,25 @@ __host__ __device__ inline int64_t attn_extent_bytes(const AaAttnOperand& x, int
 // KT = keys per tile: 64, or 32 for single-tile sequences of at most 32 keys (the T' = 17 temporal attention: half the LDS,
 // half the DMA instructions and half the MFMAs of a 64-key tile whose second half would be masked anyway; one-wave
 // workgroups at four per SIMD - that kernel is bound by how many independent sequences a CU keeps in flight).
-template <typename T, int NW, int KT = 64>
-__global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) attention_kernel(const AaAttention p) {
+// G > 1 (single-tile sequences only): a workgroup carries G INDEPENDENT sequences, one per wave, each with its own LDS tile - the
+// 17-frame temporal attention of the 64x64 level is 40960 one-wave sequences per call, and one-wave workgroups are launched
+// more slowly than they finish.
+template <typename T, int NW, int KT = 64, int G = 1>
+__global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) attention_kernel(const AaAttention p) {
     constexpr int PER = (KT / 4) / NW;           // DMA instructions per wave and tile (KT/8 for K + KT/8 for V in total)
     constexpr int KB = KT / 32;                  // 32-key blocks per tile
     constexpr int TILE_BYTES = 2 * KT * 128;
     static_assert(KT == 64 || (KT == 32 && NW == 1), "tile");
+    static_assert(G == 1 || NW == 1, "independent sequences per wave");
     constexpr unsigned OOB = 0x80000000u;
-    char* lds = dyn_smem();
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = wave_id();
+    const int wave = G > 1 ? 0 : wave_id();
     const int h = lane >> 5, ql = lane & 31;
     const int head = blockIdx.y;
-    const int seq = blockIdx.z;
+    const int seq = G > 1 ? blockIdx.z * G + wave_id() : blockIdx.z;
+    if (G > 1 && seq >= p.n_outer * p.n_inner) return;
+    char* lds = dyn_smem() + (G > 1 ? wave_id() * TILE_BYTES : 0);
     const int o = seq / p.n_inner, i = seq - o * p.n_inner;
     const int q0 = (blockIdx.x * NW + wave) * 32;
     const bool wave_active = q0 < p.q_len;
@@ -149,7 +154,7 @@ __global__ void __launch_bounds__(64 * NW, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) atte
     const int vf_off = (2 * h) * 256 + ((lane & 15) >> 2) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     for (int kt = 0; kt < ntiles; ++kt) {
         if (kt + 1 < ntiles) dma_wait<PER>(); else dma_wait<0>();         // tile kt landed (Q fragments are older still)
-        block_barrier();                                                  // everyone's pieces; buffer (kt-1)%3 is free again
+        if constexpr (G == 1) block_barrier(); else wave_sync();          // everyone's pieces; buffer (kt-1)%3 is free again
         if (kt + 2 < ntiles) issue((kt + 2) % 3);
         if (wave_active) {
             const char* sK = lds + (stages == 1 ? 0 : (kt % 3)) * TILE_BYTES;

@@ -86,6 +86,8 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" 
 // Workgroup barrier WITHOUT the implicit vmcnt(0) drain of __syncthreads(); the "memory" clobber keeps the
 // compiler from moving LDS / DMA accesses across it.
 __device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "memory"); }
+// the lanes of a wavefront run in lock step: nothing to wait for (the host emulator, which runs lanes one after another, does)
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
 // Hand-issued LDS fragment read: `dst` is written asynchronously (lgkmcnt); hipcc neither counts it nor waits
 // for it, so every consumer must sit behind lds_wait<N>() / lds_pin() naming the register (cdna guide 5.7).

@@ -259,6 +259,7 @@ inline u32x2 lds_read_tr16_b64(const void* lds_ptr) {
 template <int N>
 inline void dma_wait() {}                       // the emulator's DMA is synchronous
 inline void block_barrier() { emu::block_barrier(); }
+inline void wave_sync() { emu::wave_barrier(); }
 
 inline void lds_read16_async(u32x4& dst, const void* lds_ptr) { dst = *reinterpret_cast<const u32x4*>(lds_ptr); }
 template <int N>

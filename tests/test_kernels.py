@@ -279,6 +279,33 @@ def test_attention_temporal(backend):
     close(o, ref, tol=1e-2)
 
 
+def test_attention_temporal_many_short_sequences(backend):
+    """>= 256 sequences of at most 32 positions run four per workgroup (one per wave, each with its own LDS tile); the count is
+    not a multiple of four, so the last workgroup has idle waves."""
+    clips, frames, hw, heads = 2, 17, 129, 1
+    C = heads * 64
+    qkv = rnd(clips * frames * hw, 3 * C, seed=38)
+    st = (frames * hw, 1, hw)
+    o = ops.attention(qkv, 0, qkv, C, qkv, 2 * C, heads, clips, hw, frames, frames, st, st)
+    x = qkv.reshape(clips, frames, hw, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)
+    ref = sdpa(x[0], x[1], x[2]).permute(0, 3, 1, 2, 4).reshape(-1, C)
+    close(o, ref, tol=1e-2)
+
+
+@pytest.mark.gpu
+def test_attention_temporal_eight_sequences_per_workgroup():
+    """>= 4096 short sequences: eight per workgroup (the 64x64 level's temporal attention); 2 x 2053 sequences, not a multiple of 8."""
+    clips, frames, hw, heads = 2, 17, 2053, 2
+    C = heads * 64
+    g = torch.Generator().manual_seed(39)
+    qkv = torch.randn(clips * frames * hw, 3 * C, generator=g).to(torch.float16).to("cuda")
+    st = (frames * hw, 1, hw)
+    o = ops.attention(qkv, 0, qkv, C, qkv, 2 * C, heads, clips, hw, frames, frames, st, st)
+    x = qkv.reshape(clips, frames, hw, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)
+    ref = sdpa(x[0], x[1], x[2]).permute(0, 3, 1, 2, 4).reshape(-1, C)
+    close(o, ref, tol=1e-2)
+
+
 def test_softmax_rows_and_dpm_step(backend):
     g = torch.Generator().manual_seed(35)
     s = (torch.randn(5, 300, generator=g) * 4).to(DEV)
