@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Idle time between the kernels of one replayed denoising step (rocprofv3 --kernel-trace csv): the kernels between two
+consecutive cfg_dpm_step launches."""
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "cfg_dpm_step" in r["Kernel_Name"]]
+print("kernels", len(rows), "cfg steps at", idx[-6:])
+for a, b in zip(idx[-4:-1], idx[-3:]):
+    seg = rows[a + 1:b + 1]
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg)
+    span = int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])
+    gaps = [int(y["Start_Timestamp"]) - int(x["End_Timestamp"]) for x, y in zip(seg, seg[1:])]
+    pos = [g for g in gaps if g > 0]
+    hist = collections.Counter(min(g // 500, 12) for g in pos)
+    print(f"step: {len(seg)} kernels, span {span/1e6:.2f} ms, busy {busy/1e6:.2f} ms, idle {(span-busy)/1e6:.2f} ms, mean gap {sum(pos)/max(1,len(pos)):.0f} ns, "
+          f"overlaps {sum(1 for g in gaps if g < 0)}; gap histogram (0.5 us buckets): {sorted(hist.items())}")
+    worst = sorted(zip(gaps, [r['Kernel_Name'][:50] for r in seg], [r['Kernel_Name'][:50] for r in seg[1:]]), reverse=True)[:5]
+    for g, x, y in worst:
+        print(f"      {g/1e3:7.1f} us  {x} -> {y}")
