@@ -638,6 +638,27 @@ def test_x_tiles_linear_every_loop_shape(backend, cfg, N, K):
     close(y, (F.silu(x.float() @ w.float().t() + b.float()) + r.float()) * 0.5)
 
 
+@pytest.mark.parametrize("cfg,N", [(36, 256), (39, 320), (40, 256), (47, 128), (49, 320)])
+def test_x_tiles_per_row_bias_and_plain_forms(backend, cfg, N):
+    """The hand-scheduled tiles start their accumulators from the bias - except a PER-ROW bias, which the general epilogue adds;
+    and the branch-free epilogue forms one by one: bias only, + row vector, + residual with scales."""
+    from animate_anything_amd import _lib
+    M, K = 333, 192
+    x, w, b = rnd(M, K, seed=211), rnd(N, K, scale=0.1, seed=212), rnd(N, seed=213)
+    brow, r, rv = rnd(M, seed=214), rnd(M, N, seed=215), rnd(3, N, seed=216)
+    h = x.float() @ w.float().t()
+    lib = _lib.get()
+    lib.aa_set_tile_override(cfg)
+    try:
+        close(ops.conv_gemm(x, ops.pack_weight(w, None), ops.linear_geom(M), bias=brow, bias_per_row=True), h + brow.float()[:, None])
+        close(ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M)), h + b.float())
+        close(ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M), rowvec=rv, rowvec_div=111), h + b.float() + rv.float().repeat_interleave(111, 0))
+        close(ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M), residual=r, acc_scale=0.5, out_scale=2.0), ((h + b.float()) * 0.5 + r.float()) * 2.0)
+        close(ops.conv_gemm(x, ops.pack_weight(w, None), ops.linear_geom(M), residual=r), h + r.float())
+    finally:
+        lib.aa_set_tile_override(-1)
+
+
 @pytest.mark.parametrize("cfg,N", X_TILES)
 def test_x_tiles_temporal_conv_and_two_sources(backend, cfg, N):
     """(3,1,1) temporal convolution (taps = row shifts of H*W, clip borders masked) and a 3x3 convolution over the channel
