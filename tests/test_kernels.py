@@ -178,6 +178,29 @@ def test_groupnorm_one_pass_equals_two_pass(backend, C, hw, frames, c1):
     close(y1, y2.float(), tol=2e-3)
 
 
+def test_groupnorm_one_pass_bf16(backend):
+    """bf16 storage through the single-kernel GroupNorm (per-frame and clip-wide statistics), against torch in fp32."""
+    bf = torch.bfloat16
+    g0 = torch.Generator().manual_seed(161)
+    n, C, hw, groups = 4, 640, 60, 32
+    x = (torch.randn(n * hw, C, generator=g0) * 1.2 + 0.3).to(bf).to(DEV)
+    gamma, beta = torch.randn(C, generator=g0).to(bf).to(DEV), torch.randn(C, generator=g0).to(bf).to(DEV)
+    ops.GN_PLANS = []
+    tune, ops.AUTOTUNE = ops.AUTOTUNE, False
+    try:
+        y2 = ops.groupnorm(x, gamma, beta, n, hw, groups, eps=1e-5, silu=True)
+        y3 = ops.groupnorm(x, gamma, beta, 2, 2 * hw, groups, eps=1e-5, silu=False)
+    finally:
+        ops.AUTOTUNE = tune
+        plans, ops.GN_PLANS = ops.GN_PLANS, None
+    assert plans[0] is not None and plans[1] is not None and y2.dtype == bf
+    xf = x.float().cpu()
+    r2 = F.silu(F.group_norm(xf.reshape(n, hw, C).permute(0, 2, 1), groups, gamma.float().cpu(), beta.float().cpu(), 1e-5)).permute(0, 2, 1).reshape(-1, C)
+    r3 = F.group_norm(xf.reshape(2, 2 * hw, C).permute(0, 2, 1), groups, gamma.float().cpu(), beta.float().cpu(), 1e-5).permute(0, 2, 1).reshape(-1, C)
+    close(y2, r2, tol=2e-2)
+    close(y3, r3, tol=2e-2)
+
+
 @pytest.mark.parametrize("C", [64, 320, 640, 1280])
 def test_layernorm(backend, C):
     x, g, b = rnd(11, C, seed=28) * 3 + 1, rnd(C, seed=29), rnd(C, seed=30)
