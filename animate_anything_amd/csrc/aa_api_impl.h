@@ -204,6 +204,12 @@ static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) 
     const int rounds = tiles_m * tiles_n / cus;
     const int rem = tiles_m * tiles_n - rounds * cus;
     if (!(rounds >= 1 && rem > 0 && rem * 8 < cus * 5)) return p;
+    {   // a leftover launch costs ~25 us (launch, first operands, a short epilogue-bound kernel: 21 us measured at the 64x64 level):
+        // only worth it when the empty part of the sparse round would cost more.  One K step of a 256 x 256 x 64 tile takes
+        // ~1.3 us on a CU, a tile's fixed costs (setup, first stage, epilogue, turnover) ~8 us (scripts/phase_probe_x.py).
+        const double t_round = (double)(d.k_pad / c.bk) * 1.3 * c.bm * c.bn / 65536.0 * (c.bk / 64.0) * c.per_cu + 8.0;
+        if (!(d.debug & 4) && (1.0 - (double)rem / cus) * t_round < 25.0) return p;
+    }
     p.m_main = (rounds * cus / tiles_n) * c.bm;
     if (p.m_main >= M) { p.m_main = M; return p; }
     const int nk = d.k_pad / c.bk;
