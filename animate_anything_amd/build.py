@@ -16,10 +16,11 @@ def _deps():
 
 
 PROBE_LIB = os.path.join(PKG, "libaa_mi355_probe.so")
+TU_GROUPS = 8             # aa_api_impl.h: tile-table entry i is compiled in unit i % TU_GROUPS
 
 
 def build(force=False, verbose=False, probe=False, ablate=0):
-    """Compile csrc/aa_api.hip -> libaa_mi355.so (skipped when up to date). Returns the path.
+    """Compile csrc/aa_api.hip + 8 x csrc/aa_tiles.hip -> libaa_mi355.so (skipped when up to date). Returns the path.
     probe=True builds the -DAA_PHASE_PROBE profiling variant (scripts/phase_probe.py) next to it;
     ablate=bits a timing-only -DAA_X_ABLATE variant of the hand-scheduled kernels (scripts/x_ablate.py)."""
     LIB = PROBE_LIB if probe else globals()["LIB"]
@@ -28,17 +29,31 @@ def build(force=False, verbose=False, probe=False, ablate=0):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _deps()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffast-math",
-           "-I", os.path.join(CSRC, "kernels", "device"), "-I", os.path.join(CSRC, "kernels"), "-I", CSRC,
-           "-I", os.path.join(ROOT, "include"),
-           os.path.join(CSRC, "aa_api.hip"), "-o", LIB]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", f"-DAA_TU_GROUPS={TU_GROUPS}",
+             "-I", os.path.join(CSRC, "kernels", "device"), "-I", os.path.join(CSRC, "kernels"), "-I", CSRC,
+             "-I", os.path.join(ROOT, "include")]
     if probe:
-        cmd.insert(1, "-DAA_PHASE_PROBE")
+        flags.insert(0, "-DAA_PHASE_PROBE")
     if ablate:
-        cmd.insert(1, f"-DAA_X_ABLATE={int(ablate)}")
+        flags.insert(0, f"-DAA_X_ABLATE={int(ablate)}")
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+        flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    # one translation unit for the C ABI + TU_GROUPS units with a slice of the contraction tile table each, compiled in parallel
+    # (a single unit took more than five minutes), linked into one shared object
+    obj_dir = os.path.join(PKG, "build", os.path.basename(LIB)[:-3])
+    os.makedirs(obj_dir, exist_ok=True)
+    jobs = [([os.path.join(CSRC, "aa_api.hip")], os.path.join(obj_dir, "aa_api.o"))]
+    jobs += [([f"-DAA_TU_GROUP={g}", os.path.join(CSRC, "aa_tiles.hip")], os.path.join(obj_dir, f"aa_tiles_{g}.o")) for g in range(TU_GROUPS)]
+
+    def compile_one(job):
+        src, obj = job
+        subprocess.check_call([hipcc] + flags + ["-c"] + src + ["-o", obj])
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
+        objs = list(pool.map(compile_one, jobs))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
     return LIB
 
 

@@ -254,64 +254,101 @@ static void cg_launch_x(const AaConvGemm& d, int m_begin, int m_end, int splits,
     AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1, RING, PER_CU>), grid, block, cgx_lds_bytes(BM, BN, BK, RING), stream, d, m_end, tiles_n, m_begin, splits);
 }
 
-template <typename T>
-static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, void* stream, int splits = 1) {
+// The contraction kernels are compiled in AA_TU_GROUPS translation units (build.py compiles them in parallel: one unit took 5+
+// minutes): tile-table entry i lives in unit i % AA_TU_GROUPS (csrc/aa_tiles.hip, -DAA_TU_GROUP=g), which instantiates
+// cg_launch_cfg_group<T, g> explicitly; everywhere else only its declaration is seen.  AA_TU_GROUPS == 1 (the emulator build,
+// ablation builds): everything in the including unit.
+#ifndef AA_TU_GROUPS
+#define AA_TU_GROUPS 1
+#endif
+template <typename T, int G>
+bool cg_launch_cfg_group(int cfg, const AaConvGemm& d, int m_begin, int m_end, void* stream, int splits) {
+#define AA_TILE(i, ...) case i: if constexpr (i % AA_TU_GROUPS == G) { __VA_ARGS__; return true; } else return false;
     switch (cfg) {
-        case 0: cg_launch_dma<T, 128, 64, 2, 2, 64, 2, 3>(d, m_begin, m_end, splits, stream); break;
-        case 1: cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2>(d, m_begin, m_end, splits, stream); break;
-        case 2: cg_launch_dma<T, 192, 256, 3, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
-        case 3: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
-        case 4: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
-        case 5: cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
-        case 6: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1>(d, m_begin, m_end, splits, stream); break;
-        case 7: cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1>(d, m_begin, m_end, splits, stream); break;
-        case 8: cg_launch_dma<T, 128, 128, 2, 2, 32, 4, 2>(d, m_begin, m_end, splits, stream); break;
-        case 9: cg_launch_dma<T, 128, 64, 2, 2, 32, 4, 3>(d, m_begin, m_end, splits, stream); break;
-        case 10: cg_launch_dma<T, 192, 320, 3, 2, 32, 4, 1>(d, m_begin, m_end, splits, stream); break;
-        case 11: cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2>(d, m_begin, m_end, splits, stream); break;
-        case 12: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2>(d, m_begin, m_end, splits, stream); break;
-        case 13: cg_launch_dma<T, 128, 256, 2, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
-        case 14: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, splits, stream); break;
-        case 15: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, splits, stream); break;
-        case 16: cg_launch_dma<T, 128, 128, 2, 2, 32, 2, 3>(d, m_begin, m_end, splits, stream); break;
-        case 17: cg_launch_dma<T, 128, 64, 2, 2, 32, 2, 4>(d, m_begin, m_end, splits, stream); break;
-        case 18: cg_launch_dma<T, 64, 128, 2, 2, 32, 2, 4>(d, m_begin, m_end, splits, stream); break;
-        case 19: cg_launch_dma<T, 64, 64, 2, 2, 32, 2, 6>(d, m_begin, m_end, splits, stream); break;
-        case 20: cg_launch_dma<T, 64, 256, 2, 2, 32, 2, 3>(d, m_begin, m_end, splits, stream); break;
-        case 21: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1, true>(d, m_begin, m_end, splits, stream); break;
-        case 22: cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1, true>(d, m_begin, m_end, splits, stream); break;
-        case 23: cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1>(d, m_begin, m_end, splits, stream); break;
-        case 24: cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1, true>(d, m_begin, m_end, splits, stream); break;
-        case 25: cg_launch_dma<T, 128, 256, 2, 4, 32, 2, 2>(d, m_begin, m_end, splits, stream); break;
-        case 26: cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream); break;
-        case 27: cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream); break;
-        case 28: cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream); break;
-        case 29: cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1, false, true>(d, m_begin, m_end, splits, stream); break;
-        case 30: cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2, false, true>(d, m_begin, m_end, splits, stream); break;
-        case 31: cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2, false, true>(d, m_begin, m_end, splits, stream); break;
-        case 32: cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream); break;
-        case 33: cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2, false, true>(d, m_begin, m_end, splits, stream); break;
-        case 34: cg_launch_slab<T, 256, 320, 4, 2>(d, m_begin, m_end, stream); break;
-        case 35: cg_launch_slab<T, 256, 256, 4, 2>(d, m_begin, m_end, stream); break;
-        case 36: cg_launch_x<T, 256, 256, 2, 2, 64, 8, 8, 0>(d, m_begin, m_end, splits, stream); break;
-        case 37: cg_launch_x<T, 256, 320, 2, 2, 64, 11, 7, 0>(d, m_begin, m_end, splits, stream); break;
-        case 38: cg_launch_x<T, 256, 256, 2, 2, 64, 6, 5, 5>(d, m_begin, m_end, splits, stream); break;
-        case 39: cg_launch_x<T, 256, 320, 2, 2, 64, 7, 6, 5>(d, m_begin, m_end, splits, stream); break;
-        case 40: cg_launch_x<T, 256, 256, 4, 2, 64, 2, 2, 2>(d, m_begin, m_end, splits, stream); break;
-        case 41: cg_launch_x<T, 256, 256, 2, 2, 32, 4, 0, 0>(d, m_begin, m_end, splits, stream); break;
-        case 42: cg_launch_x<T, 256, 320, 2, 2, 32, 5, 0, 0>(d, m_begin, m_end, splits, stream); break;
-        case 43: cg_launch_x<T, 256, 256, 4, 2, 32, 2, 0, 0>(d, m_begin, m_end, splits, stream); break;
-        case 44: cg_launch_x<T, 128, 256, 2, 2, 32, 3, 0, 0, 3, 2>(d, m_begin, m_end, splits, stream); break;
-        case 45: cg_launch_x<T, 256, 128, 4, 1, 32, 3, 0, 0, 3, 2>(d, m_begin, m_end, splits, stream); break;
-        case 46: cg_launch_x<T, 192, 256, 2, 2, 64, 5, 5, 4>(d, m_begin, m_end, splits, stream); break;
-        case 47: cg_launch_x<T, 128, 128, 2, 2, 64, 2, 2, 2, 2, 2>(d, m_begin, m_end, splits, stream); break;
-        case 48: cg_launch_x<T, 128, 128, 2, 2, 32, 2, 0, 0, 4, 2>(d, m_begin, m_end, splits, stream); break;
-        case 49: cg_launch_x<T, 192, 320, 2, 2, 64, 6, 5, 5>(d, m_begin, m_end, splits, stream); break;
+        AA_TILE(0, cg_launch_dma<T, 128, 64, 2, 2, 64, 2, 3>(d, m_begin, m_end, splits, stream))
+        AA_TILE(1, cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2>(d, m_begin, m_end, splits, stream))
+        AA_TILE(2, cg_launch_dma<T, 192, 256, 3, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream))
+        AA_TILE(3, cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream))
+        AA_TILE(4, cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream))
+        AA_TILE(5, cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream))
+        AA_TILE(6, cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1>(d, m_begin, m_end, splits, stream))
+        AA_TILE(7, cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1>(d, m_begin, m_end, splits, stream))
+        AA_TILE(8, cg_launch_dma<T, 128, 128, 2, 2, 32, 4, 2>(d, m_begin, m_end, splits, stream))
+        AA_TILE(9, cg_launch_dma<T, 128, 64, 2, 2, 32, 4, 3>(d, m_begin, m_end, splits, stream))
+        AA_TILE(10, cg_launch_dma<T, 192, 320, 3, 2, 32, 4, 1>(d, m_begin, m_end, splits, stream))
+        AA_TILE(11, cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2>(d, m_begin, m_end, splits, stream))
+        AA_TILE(12, cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2>(d, m_begin, m_end, splits, stream))
+        AA_TILE(13, cg_launch_dma<T, 128, 256, 2, 2, 64, 2, 1>(d, m_begin, m_end, splits, stream))
+        AA_TILE(14, cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(15, cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(16, cg_launch_dma<T, 128, 128, 2, 2, 32, 2, 3>(d, m_begin, m_end, splits, stream))
+        AA_TILE(17, cg_launch_dma<T, 128, 64, 2, 2, 32, 2, 4>(d, m_begin, m_end, splits, stream))
+        AA_TILE(18, cg_launch_dma<T, 64, 128, 2, 2, 32, 2, 4>(d, m_begin, m_end, splits, stream))
+        AA_TILE(19, cg_launch_dma<T, 64, 64, 2, 2, 32, 2, 6>(d, m_begin, m_end, splits, stream))
+        AA_TILE(20, cg_launch_dma<T, 64, 256, 2, 2, 32, 2, 3>(d, m_begin, m_end, splits, stream))
+        AA_TILE(21, cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(22, cg_launch_dma<T, 256, 256, 4, 2, 32, 4, 1, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(23, cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1>(d, m_begin, m_end, splits, stream))
+        AA_TILE(24, cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(25, cg_launch_dma<T, 128, 256, 2, 4, 32, 2, 2>(d, m_begin, m_end, splits, stream))
+        AA_TILE(26, cg_launch_dma<T, 256, 320, 4, 2, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(27, cg_launch_dma<T, 256, 256, 4, 2, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(28, cg_launch_dma<T, 192, 256, 2, 4, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(29, cg_launch_dma<T, 256, 320, 4, 2, 32, 4, 1, false, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(30, cg_launch_dma<T, 128, 320, 2, 2, 32, 2, 2, false, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(31, cg_launch_dma<T, 128, 128, 2, 2, 64, 2, 2, false, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(32, cg_launch_dma<T, 192, 320, 3, 2, 64, 2, 1, false, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(33, cg_launch_dma<T, 128, 256, 2, 2, 32, 2, 2, false, true>(d, m_begin, m_end, splits, stream))
+        AA_TILE(34, cg_launch_slab<T, 256, 320, 4, 2>(d, m_begin, m_end, stream))
+        AA_TILE(35, cg_launch_slab<T, 256, 256, 4, 2>(d, m_begin, m_end, stream))
+        AA_TILE(36, cg_launch_x<T, 256, 256, 2, 2, 64, 8, 8, 0>(d, m_begin, m_end, splits, stream))
+        AA_TILE(37, cg_launch_x<T, 256, 320, 2, 2, 64, 11, 7, 0>(d, m_begin, m_end, splits, stream))
+        AA_TILE(38, cg_launch_x<T, 256, 256, 2, 2, 64, 6, 5, 5>(d, m_begin, m_end, splits, stream))
+        AA_TILE(39, cg_launch_x<T, 256, 320, 2, 2, 64, 7, 6, 5>(d, m_begin, m_end, splits, stream))
+        AA_TILE(40, cg_launch_x<T, 256, 256, 4, 2, 64, 2, 2, 2>(d, m_begin, m_end, splits, stream))
+        AA_TILE(41, cg_launch_x<T, 256, 256, 2, 2, 32, 4, 0, 0>(d, m_begin, m_end, splits, stream))
+        AA_TILE(42, cg_launch_x<T, 256, 320, 2, 2, 32, 5, 0, 0>(d, m_begin, m_end, splits, stream))
+        AA_TILE(43, cg_launch_x<T, 256, 256, 4, 2, 32, 2, 0, 0>(d, m_begin, m_end, splits, stream))
+        AA_TILE(44, cg_launch_x<T, 128, 256, 2, 2, 32, 3, 0, 0, 3, 2>(d, m_begin, m_end, splits, stream))
+        AA_TILE(45, cg_launch_x<T, 256, 128, 4, 1, 32, 3, 0, 0, 3, 2>(d, m_begin, m_end, splits, stream))
+        AA_TILE(46, cg_launch_x<T, 192, 256, 2, 2, 64, 5, 5, 4>(d, m_begin, m_end, splits, stream))
+        AA_TILE(47, cg_launch_x<T, 128, 128, 2, 2, 64, 2, 2, 2, 2, 2>(d, m_begin, m_end, splits, stream))
+        AA_TILE(48, cg_launch_x<T, 128, 128, 2, 2, 32, 2, 0, 0, 4, 2>(d, m_begin, m_end, splits, stream))
+        AA_TILE(49, cg_launch_x<T, 192, 320, 2, 2, 64, 6, 5, 5>(d, m_begin, m_end, splits, stream))
         default: return false;
     }
-    return true;
+#undef AA_TILE
+}
+#if AA_TU_GROUPS > 1
+#define AA_X(g) extern template bool cg_launch_cfg_group<f16_t, g>(int, const AaConvGemm&, int, int, void*, int); \
+                extern template bool cg_launch_cfg_group<bf16_t, g>(int, const AaConvGemm&, int, int, void*, int);
+AA_X(0) AA_X(1) AA_X(2) AA_X(3) AA_X(4) AA_X(5) AA_X(6) AA_X(7)
+#undef AA_X
+static_assert(AA_TU_GROUPS == 8, "aa_tiles.hip is compiled once per group: keep build.py and this list in step");
+#endif
+
+template <typename T>
+static bool cg_launch_cfg(int cfg, const AaConvGemm& d, int m_begin, int m_end, void* stream, int splits = 1) {
+    if (cfg < 0) return false;
+#if AA_TU_GROUPS > 1
+    switch (cfg % AA_TU_GROUPS) {
+        case 0: return cg_launch_cfg_group<T, 0>(cfg, d, m_begin, m_end, stream, splits);
+        case 1: return cg_launch_cfg_group<T, 1>(cfg, d, m_begin, m_end, stream, splits);
+        case 2: return cg_launch_cfg_group<T, 2>(cfg, d, m_begin, m_end, stream, splits);
+        case 3: return cg_launch_cfg_group<T, 3>(cfg, d, m_begin, m_end, stream, splits);
+        case 4: return cg_launch_cfg_group<T, 4>(cfg, d, m_begin, m_end, stream, splits);
+        case 5: return cg_launch_cfg_group<T, 5>(cfg, d, m_begin, m_end, stream, splits);
+        case 6: return cg_launch_cfg_group<T, 6>(cfg, d, m_begin, m_end, stream, splits);
+        default: return cg_launch_cfg_group<T, 7>(cfg, d, m_begin, m_end, stream, splits);
+    }
+#else
+    return cg_launch_cfg_group<T, 0>(cfg, d, m_begin, m_end, stream, splits);
+#endif
 }
 
+#ifdef AA_TU_TILES_ONLY             // (csrc/aa_tiles.hip stops here: the launchers of one group, nothing of the API)
+}  // namespace aa
+#else
 template <typename T>
 static int conv_gemm_t(const AaConvGemm& d, void* stream) {
     const int M = (int)((int64_t)d.n_img * d.h_out * d.w_out);
@@ -708,3 +745,4 @@ int aa_cfg_euler_step_tokens(const AaEulerStepTok* d, void* stream) {
 }
 
 }  // extern "C"
+#endif  // AA_TU_TILES_ONLY

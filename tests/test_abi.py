@@ -49,25 +49,38 @@ def test_missing_library_fails_loudly(tmp_path):
         raise AssertionError("binding a missing library must raise")
 
 
-def _device_code_object(tmp_path):
-    """The gfx950 code object inside libaa_mi355.so (clang offload bundle)."""
+def _device_code_objects(tmp_path):
+    """The gfx950 code objects inside libaa_mi355.so: one clang offload bundle per translation unit (csrc/aa_api.hip and the
+    groups of csrc/aa_tiles.hip)."""
     import struct
     from animate_anything_amd import build
     data = open(build.build(), "rb").read()
-    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
-    assert i >= 0
-    n = struct.unpack_from("<Q", data, i + 24)[0]
-    off = i + 32
-    for _ in range(n):
-        o, s, ln = struct.unpack_from("<QQQ", data, off)
-        off += 24
-        name = data[off:off + ln].decode()
-        off += ln
-        if "gfx950" in name:
-            p = tmp_path / "dev.co"
-            p.write_bytes(data[i + o:i + o + s])
-            return str(p)
-    raise AssertionError("no gfx950 code object in the library")
+    out, start = [], 0
+    while True:
+        i = data.find(b"__CLANG_OFFLOAD_BUNDLE__", start)
+        if i < 0:
+            break
+        start = i + 24
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        if not 0 < n < 16:
+            continue
+        off = i + 32
+        for _ in range(n):
+            o, s_, ln = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            name = data[off:off + ln].decode(errors="replace")
+            off += ln
+            if "gfx950" in name and s_ > 0:
+                p = tmp_path / f"dev{len(out)}.co"
+                p.write_bytes(data[i + o:i + o + s_])
+                out.append(str(p))
+    assert out, "no gfx950 code object in the library"
+    return out
+
+
+def _device_code_object(tmp_path):
+    """(the unit that holds the first tile group: scripts that only need some contraction kernels)"""
+    return _device_code_objects(tmp_path)[0]
 
 
 def test_x_kernels_keep_hipcc_out_of_the_accumulators(tmp_path):
@@ -81,14 +94,14 @@ def test_x_kernels_keep_hipcc_out_of_the_accumulators(tmp_path):
     tools = "/opt/rocm/lib/llvm/bin"
     if not shutil.which(os.path.join(tools, "llvm-objdump")):
         pytest.skip("llvm-objdump not available")
-    co = _device_code_object(tmp_path)
-    notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    cos = _device_code_objects(tmp_path)
+    notes = "".join(subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout for co in cos)
     meta = {}
     for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
         meta[m.group(2)] = tuple(int(m.group(k)) for k in (1, 3, 4, 5))
     xk = {k: v for k, v in meta.items() if "conv_gemm_x_kernel" in k}
     assert len(xk) >= 16                                    # 8 tiles x {fp16, bf16}
-    dis = subprocess.run([os.path.join(tools, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+    dis = "".join(subprocess.run([os.path.join(tools, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout for co in cos)
     bodies = {}
     cur = None
     for line in dis.split("\n"):
