@@ -251,7 +251,10 @@ template <typename T, int BM, int BN, int WM, int WN, int BK, int DP3, int DP0, 
 static void cg_launch_x(const AaConvGemm& d, int m_begin, int m_end, int splits, void* stream) {
     const int tiles_n = d.n_pad / BN;
     const dim3 grid(((m_end - m_begin + BM - 1) / BM) * tiles_n, splits), block(64 * WM * WN);
-    AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1, RING, PER_CU>), grid, block, cgx_lds_bytes(BM, BN, BK, RING), stream, d, m_end, tiles_n, m_begin, splits);
+    if (d.kh * d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0)
+        AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1, RING, PER_CU, true>), grid, block, cgx_lds_bytes(BM, BN, BK, RING), stream, d, m_end, tiles_n, m_begin, splits);
+    else
+        AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1, RING, PER_CU, false>), grid, block, cgx_lds_bytes(BM, BN, BK, RING), stream, d, m_end, tiles_n, m_begin, splits);
 }
 
 // The contraction kernels are compiled in AA_TU_GROUPS translation units (build.py compiles them in parallel: one unit took 5+

@@ -43,7 +43,9 @@ __host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring) {
 // 5440 empty workgroups costs 6.5 us, scripts/probe/dispatch_cost.hip.  Not kept.)
 // PER_CU = workgroups meant to be co-resident on a CU (two 4-wave workgroups drift out of phase: one multiplies while the
 // other runs its epilogue - the VALU-heavy GEGLU epilogue is as long as a K = 320 loop).
-template <typename T, int BM, int BN, int WM, int WN, int BK, int DP3, int DP0, int DP1, int RING = (BK == 64 ? 2 : 4), int PER_CU = 1>
+// LIN: the call is a plain linear layer / 1x1 convolution (one tap, stride 1, no padding): the per-row pixel arithmetic (two
+// integer divisions per fed row), the tap masks and the tap walk of the K position are compiled out of the setup.
+template <typename T, int BM, int BN, int WM, int WN, int BK, int DP3, int DP0, int DP1, int RING = (BK == 64 ? 2 : 4), int PER_CU = 1, bool LIN = false>
 __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv_gemm_x_kernel(const AaConvGemm p, const int M, const int tiles_n, const int m_begin, const int k_splits) {
     constexpr int STAGES = RING;
     static_assert(BK == 64 ? RING == 2 : (RING == 3 || RING == 4), "ring depth");
@@ -105,7 +107,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const int kbase = blockIdx.y * k_per;
     const int nk = max(0, min(k_per, nk_all - kbase));
     // (convolutions behind a nearest-neighbour resize - Upsample2D - stay with conv_gemm_dma.h: aa_conv_gemm_tile_ok)
-    const bool linear = p.kh * p.kw == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0;
+    const bool linear = LIN || (p.kh * p.kw == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0);
+    const int kh_ = LIN ? 1 : p.kh, kw_ = LIN ? 1 : p.kw;
 
     // ---- DMA geometry (as conv_gemm_dma.h): this lane feeds LDS rows ((wave + NW*j)*RPI + lane/SPR), 16-byte position lane%SPR
     constexpr unsigned OOB = 0x80000000u;
@@ -138,15 +141,15 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         const RowCoords rc = row_coords(j);
         const int iy = rc.iy, ix = rc.ix;
         pix[j] = (rc.img * p.h_in + iy) * p.w_in + ix;                             // may be "negative": only used for in-range taps
-        const int ylo = max(0, -iy), yhi = max(ylo, min(p.kh, p.h_virt - iy));
-        const int xlo = max(0, -ix), xhi = max(xlo, min(p.kw, p.w_virt - ix));
+        const int ylo = max(0, -iy), yhi = max(ylo, min(kh_, p.h_virt - iy));
+        const int xlo = max(0, -ix), xhi = max(xlo, min(kw_, p.w_virt - ix));
         const unsigned my = ((1u << yhi) - 1u) ^ ((1u << ylo) - 1u), mx = ((1u << xhi) - 1u) ^ ((1u << xlo) - 1u);
         vmask[j] = rc.ok ? (my | (mx << 8)) : 0u;
     }
     // weight panel: this lane's row of piece 0; piece j is NW * RPI rows further (a wave-uniform offset)
     const unsigned wb0 = (unsigned)((tile_n * BN + wave * RPI + lrow) * p.k_pad) * 2u + slot16;
     const unsigned wb_step = (unsigned)(NW * RPI * p.k_pad) * 2u;
-    const int taps = p.kh * p.kw;
+    const int taps = kh_ * kw_;
 
     // K position of the next prepare() call (wave-uniform scalars, advanced incrementally; see conv_gemm_dma.h)
     int n_tap, n_dy, n_dx, n_cb;
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         const int k0 = kbase * BK;
         if (p.k_order) { const int unit = k0 >> 6; const int chunk = unit / taps; n_tap = unit - chunk * taps; n_cb = chunk * 64 + (k0 & 63); }
         else           { n_tap = k0 / ctot; n_cb = k0 - n_tap * ctot; }
-        n_dy = n_tap / p.kw; n_dx = n_tap - n_dy * p.kw;
+        n_dy = n_tap / kw_; n_dx = n_tap - n_dy * kw_;
     }
     int cur_tap = -1, cur_src = -1;
     unsigned pb[AJ];                     // byte offset of each fed row's source pixel for the current (tap, source) (OOB = halo / tail)
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     auto prepare = [&](int kt, int buf) {
         const int tap = n_tap, cb = n_cb, dy = n_dy, dx = n_dx;
         {
-            const bool wrap_x = n_dx + 1 == p.kw;
+            const bool wrap_x = n_dx + 1 == kw_;
             if (p.k_order) {
                 const bool half = BK == 32 && !(n_cb & 32);              // first half of a 64-channel unit: same tap
                 const bool last_tap = n_tap + 1 == taps;
