@@ -228,11 +228,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     // one register per fragment row block, the sub-step is an XOR constant inside the read statement
     const int frow = lane & 31, fh = lane >> 5;
     int a_off[MI], w_off[NI];
+    auto fragment_offsets = [&]() __attribute__((always_inline)) {        // (called behind the first DMA issue: nothing waits for it)
 #pragma unroll
-    for (int i = 0; i < MI; ++i) { const int rr = wm * (BM / WM) + i * 32 + frow; a_off[i] = rr * ROWB + ((fh ^ ((rr / RPB) & swm)) << 4); }
-    const int prow = (frow & 3) + 4 * (frow >> 3) + 16 * ((frow >> 2) & 1);          // permuted weight rows: conv_gemm_dma.h
+        for (int i = 0; i < MI; ++i) { const int rr = wm * (BM / WM) + i * 32 + frow; a_off[i] = rr * ROWB + ((fh ^ ((rr / RPB) & swm)) << 4); }
+        const int prow = (frow & 3) + 4 * (frow >> 3) + 16 * ((frow >> 2) & 1);      // permuted weight rows: conv_gemm_dma.h
 #pragma unroll
-    for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + prow; w_off[j] = BM * ROWB + rr * ROWB + ((fh ^ ((rr / RPB) & swm)) << 4); }
+        for (int j = 0; j < NI; ++j) { const int rr = wn * (BN / WN) + j * 32 + prow; w_off[j] = BM * ROWB + rr * ROWB + ((fh ^ ((rr / RPB) & swm)) << 4); }
+    };
     static_assert(STAGE_BYTES % ROWB == 0 && ROWB % 64 == 0 && (BM * ROWB) % 256 == 0, "XOR addressing of the k sub-steps");
 
     AccFile af;
@@ -311,6 +313,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             stamp(1);
             dma_range(IntTag<0>(), IntTag<PER_TILE>());
             if (nk > 1) { prepare(1, 1); dma_range(IntTag<0>(), IntTag<DP3>()); }
+            fragment_offsets();
             put_bias();
             if (nk > 1) dma_wait<DP3>(); else dma_wait<0>();
             block_barrier();
@@ -352,6 +355,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
                 if (nk > k) { prepare(k, k); dma_range(IntTag<0>(), IntTag<PER_TILE>()); }
             });
             if (nk > RING - 1) { prepare(RING - 1, RING - 1); dma_range(IntTag<0>(), IntTag<DPB>()); }
+            fragment_offsets();
             put_bias();
             if (nk > RING - 1) dma_wait<(RING - 2) * PER_TILE + DPB>();
             else if (RING == 4 && nk == 3) dma_wait<2 * PER_TILE>();
