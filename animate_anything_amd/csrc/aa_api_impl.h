@@ -553,6 +553,11 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream) {
     if (!aligned16(d->a0) || !aligned16(d->a1) || !aligned16(d->w)) return fail(AA_E_ALIGN, "conv_gemm: operands must be 16-byte aligned");
     if (d->out_dtype != AA_F32 && d->out_dtype != d->dtype) return fail(AA_E_DTYPE, "conv_gemm: out_dtype must be dtype or f32");
     if (d->act != AA_ACT_NONE && d->act != AA_ACT_SILU) return fail(AA_E_SHAPE, "conv_gemm: activation %d is not fused here (AA_ACT_NONE / AA_ACT_SILU)", d->act);
+    // a tile named in the descriptor is a demand, not a hint: a call it cannot carry out fails (it used to fall through to the
+    // automatic choice, so a "forced tile" test could pass without running that tile).  The thread-local override of
+    // aa_set_tile_override stays a preference ("every following call whose packed width it divides").
+    if (d->tile >= 0 && !aa_conv_gemm_tile_ok(d, d->tile))
+        return fail(AA_E_SHAPE, "conv_gemm: tile %d (AaConvGemm.tile) cannot carry out this call (aa_conv_gemm_tile_ok == 0)", d->tile);
     if (d->dtype == AA_F16) return conv_gemm_t<f16_t>(*d, stream);
     if (d->dtype == AA_BF16) return conv_gemm_t<bf16_t>(*d, stream);
     return fail(AA_E_DTYPE, "conv_gemm: unsupported dtype %d", d->dtype);

@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     static_assert(BK == 64 || BK == 32, "K step");
     static_assert(DP2 >= 0 && DP3 >= 0 && DP0 >= 0 && DP1 >= 0 && (BK == 64 || (DP0 == 0 && DP1 == 0)), "DMA schedule");
     static_assert(BN * 2 <= 1024, "bias slice");
+    static_assert(AJ <= NB, "one activation row offset per MFMA gap of a sub-step");
     char* smem = dyn_smem();
     char* dummy = smem + STAGES * STAGE_BYTES;
     T* sBias = reinterpret_cast<T*>(dummy + 1024);
@@ -112,16 +113,22 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 
     // ---- DMA geometry (as conv_gemm_dma.h): this lane feeds LDS rows ((wave + NW*j)*RPI + lane/SPR), 16-byte position lane%SPR
     constexpr unsigned OOB = 0x80000000u;
-    const BufRsrc r_a0 = make_rsrc(p.a0, (unsigned)((int64_t)p.n_img * p.h_in * p.w_in * p.c0 * 2));
-    const BufRsrc r_a1 = make_rsrc(p.a1, p.c1 ? (unsigned)((int64_t)p.n_img * p.h_in * p.w_in * p.c1 * 2) : 0u);
+    // (the activation descriptors start `margin` pixels in front of the tensors: see pixi[] below; lanes that would read there
+    // carry an out-of-range offset)
+    const int margin_px = linear ? 0 : p.pad_h * p.w_in + p.pad_w;
+    const BufRsrc r_a0 = make_rsrc(static_cast<const char*>(p.a0) - (int64_t)margin_px * p.c0 * 2, (unsigned)(((int64_t)p.n_img * p.h_in * p.w_in + margin_px) * p.c0 * 2));
+    const BufRsrc r_a1 = make_rsrc(p.c1 ? static_cast<const char*>(p.a1) - (int64_t)margin_px * p.c1 * 2 : nullptr, p.c1 ? (unsigned)(((int64_t)p.n_img * p.h_in * p.w_in + margin_px) * p.c1 * 2) : 0u);
     const BufRsrc r_w = make_rsrc(p.w, (unsigned)((int64_t)p.n_pad * p.k_pad * 2));
     constexpr int swm = SPR - 1;
     const bool two_src = p.c1 != 0;
     const int lrow = lane / SPR, lpos = lane % SPR;
-    // per fed activation row: its top-left tap pixel, and which taps read a real pixel (bits 0..7 rows dy, 8..15 columns dx;
-    // 0 for rows outside the tile).  The lane's swizzled 16-byte k-slot is the same for every piece (RPI * NW rows apart).
-    int pix[AJ];
-    unsigned vmask[AJ];
+    // The lane's swizzled 16-byte k-slot is the same for every piece (RPI * NW rows apart).
+    // Per fed activation row: the pixel under tap (0, 0), counted from `margin` pixels in front of the tensor (>= 0 for every
+    // row), and one bit per tap that does NOT read a real pixel (halo, rows behind the tile; bits >= taps are set).  The source
+    // offset of a piece is then three VALU instructions per row and tap, with no branch (im2col_offset): they ride in MFMA gaps.
+    // (Round 3 recomputed the offsets in a cluster of ~75 compiler-scheduled, exec-masked instructions behind every barrier -
+    // with the tap changing every K step (k_order 1) that cluster drained the matrix pipe for ~15 % of a K step.)
+    unsigned pixi[AJ], inv[AJ];
     struct RowCoords { int img, iy, ix; bool ok; };
     auto row_coords = [&](int j) __attribute__((always_inline)) {
         const int rr = (wave + NW * j) * RPI + lrow;
@@ -140,11 +147,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     for (int j = 0; j < AJ; ++j) {
         const RowCoords rc = row_coords(j);
         const int iy = rc.iy, ix = rc.ix;
-        pix[j] = (rc.img * p.h_in + iy) * p.w_in + ix;                             // may be "negative": only used for in-range taps
+        pixi[j] = (unsigned)((rc.img * p.h_in + iy) * p.w_in + ix + margin_px);
         const int ylo = max(0, -iy), yhi = max(ylo, min(kh_, p.h_virt - iy));
         const int xlo = max(0, -ix), xhi = max(xlo, min(kw_, p.w_virt - ix));
-        const unsigned my = ((1u << yhi) - 1u) ^ ((1u << ylo) - 1u), mx = ((1u << xhi) - 1u) ^ ((1u << xlo) - 1u);
-        vmask[j] = rc.ok ? (my | (mx << 8)) : 0u;
+        const unsigned mx = ((1u << xhi) - 1u) ^ ((1u << xlo) - 1u);
+        unsigned valid = 0u;
+        for (int dy = ylo; dy < yhi; ++dy) valid |= mx << (dy * kw_);
+        inv[j] = rc.ok ? ~valid : ~0u;
     }
     // weight panel: this lane's row of piece 0; piece j is NW * RPI rows further (a wave-uniform offset)
     const unsigned wb0 = (unsigned)((tile_n * BN + wave * RPI + lrow) * p.k_pad) * 2u + slot16;
@@ -159,12 +168,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         else           { n_tap = k0 / ctot; n_cb = k0 - n_tap * ctot; }
         n_dy = n_tap / kw_; n_dx = n_tap - n_dy * kw_;
     }
-    int cur_tap = -1, cur_src = -1;
-    unsigned pb[AJ];                     // byte offset of each fed row's source pixel for the current (tap, source) (OOB = halo / tail)
+    int cur_src = -1;
+    unsigned pb[AJ];                     // byte offset of each fed row's source pixel for the prepared (tap, source) (bit 31 = halo / tail)
     bool is_src1 = false;
     unsigned is_ccb = 0u, is_kb = 0u;
     int is_buf = 0;
-    auto prepare = [&](int kt, int buf) {
+    unsigned s_c2 = 0u, s_sh = 0u;       // prepared (tap, source): bytes per pixel of the source; 31 - tap
+    unsigned v_t = 0u;                   // slot16 + byte offset of the tap's pixel from tap (0, 0)
+    auto prep_row = [&](auto j_) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_)::value;
+        im2col_offset(pb[j], pixi[j], s_c2, v_t, s_sh, inv[j]);
+    };
+    // wave-uniform part of prepare(): advances the K position, leaves what the DMA pieces of tile kt need besides pb[]
+    auto prep_scalars = [&](int kt, int buf) __attribute__((always_inline)) {
         const int tap = n_tap, cb = n_cb, dy = n_dy, dx = n_dx;
         {
             const bool wrap_x = n_dx + 1 == kw_;
@@ -186,21 +202,21 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             }
         }
         is_src1 = cb >= p.c0;
-        const int src = is_src1 ? 1 : 0;
-        if (tap != cur_tap || src != cur_src) {
-            cur_tap = tap; cur_src = src;
-            const bool tap_ok = tap < taps;
-            const int csrc = is_src1 ? p.c1 : p.c0;
-            const int d = dy * p.w_in + dx;
-#pragma unroll
-            for (int j = 0; j < AJ; ++j) {
-                const bool ok = tap_ok && (((vmask[j] >> dy) & (vmask[j] >> (8 + dx))) & 1u);
-                pb[j] = ok ? (unsigned)((pix[j] + d) * csrc) * 2u + slot16 : OOB;
-            }
-        }
+        s_c2 = (unsigned)(is_src1 ? p.c1 : p.c0) * 2u;
+        s_sh = (unsigned)(31 - min(tap, 31));                          // taps past the filter (K padding) hit a set bit: zeros
+        v_t = slot16 + (unsigned)(dy * p.w_in + dx) * s_c2;
         is_ccb = (unsigned)(is_src1 ? cb - p.c0 : cb) * 2u;
         is_kb = (unsigned)((kbase + kt) * BK) * 2u;
         is_buf = buf;
+        if constexpr (LIN) {             // one tap: the offsets only change with the source (once per K loop of a two-source call)
+            const int src = is_src1 ? 1 : 0;
+            if (src != cur_src) { cur_src = src; static_for<AJ>(prep_row); }
+        }
+    };
+    // prologue form: scalars and every row at once (inside the K loop the rows ride in MFMA gaps: substep())
+    auto prepare = [&](int kt, int buf) __attribute__((always_inline)) {
+        prep_scalars(kt, buf);
+        if constexpr (!LIN) static_for<AJ>(prep_row);
     };
     // DMA piece JJ of the prepared tile: pieces < AJ feed activation rows, the rest weight rows.  The wave-uniform parts
     // of the source address (channel chunk; K position and piece row of the weights) travel in the scalar offset.
@@ -274,14 +290,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     };
     // One sub-step: NB MFMAs out of fragment set ks&1; the gap behind MFMA g carries read g of the NEXT sub-step (g < R,
     // from stage `st_rd`, sub-step KSN) and / or DMA piece (DJ0 + g - G0) of the prepared tile for g in [G0, G0 + DN).
-    auto substep = [&](auto ks_, auto ksn_, const char* st_rd, const bool do_read, auto dj0_, auto dn_) __attribute__((always_inline)) {
+    // PREP: the gaps behind the first AJ MFMAs also carry the source offsets of the prepared tile's activation rows (its pieces
+    // follow in later gaps of this sub-step or in the next K step).
+    auto substep = [&](auto ks_, auto ksn_, const char* st_rd, const bool do_read, auto dj0_, auto dn_, auto prep_) __attribute__((always_inline)) {
         constexpr int ks = decltype(ks_)::value, ksn = decltype(ksn_)::value, set = ks & 1;
         constexpr int DJ0 = decltype(dj0_)::value, DN = decltype(dn_)::value;
+        constexpr bool PREP = decltype(prep_)::value && !LIN;
         constexpr int G0 = (DN <= NB - R) ? R : NB - DN;              // DMA pieces prefer the read-free gaps at the end
         static_for<NB>([&](auto g_) __attribute__((always_inline)) {
             constexpr int g = decltype(g_)::value, i = g / NI, j = g % NI;
             acc_mfma<i * NI + j>(af, T(), fw[set][j], fa[set][i]);
             if constexpr (g < R) { if (do_read) frag_read(st_rd, IntTag<ksn>(), IntTag<set ^ 1>(), IntTag<g>()); }
+            if constexpr (PREP && g < AJ) prep_row(IntTag<g>());
             if constexpr (DN > 0 && g >= G0 && g < G0 + DN) dma_piece(IntTag<DJ0 + g - G0>());
         });
         lds_wait_all();
@@ -292,15 +312,15 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         constexpr bool HAS_NEXT = decltype(has_next_)::value, HAS_NEXT2 = decltype(has_next2_)::value;
         const char* st = smem + (kt & 1) * STAGE_BYTES;
         const char* st_next = smem + ((kt + 1) & 1) * STAGE_BYTES;
-        substep(IntTag<0>(), IntTag<1>(), st, true, IntTag<DP3>(), IntTag<HAS_NEXT ? DP0 : 0>());
-        substep(IntTag<1>(), IntTag<2>(), st, true, IntTag<DP3 + DP0>(), IntTag<HAS_NEXT ? DP1 : 0>());
-        substep(IntTag<2>(), IntTag<3>(), st, true, IntTag<DP3 + DP0 + DP1>(), IntTag<HAS_NEXT ? DP2 : 0>());
+        substep(IntTag<0>(), IntTag<1>(), st, true, IntTag<DP3>(), IntTag<HAS_NEXT ? DP0 : 0>(), BoolTag<false>());
+        substep(IntTag<1>(), IntTag<2>(), st, true, IntTag<DP3 + DP0>(), IntTag<HAS_NEXT ? DP1 : 0>(), BoolTag<false>());
+        substep(IntTag<2>(), IntTag<3>(), st, true, IntTag<DP3 + DP0 + DP1>(), IntTag<HAS_NEXT ? DP2 : 0>(), BoolTag<false>());
         if constexpr (HAS_NEXT) {
             if constexpr (!(AA_X_ABLATE & 64)) dma_wait<0>();    // my pieces of tile kt+1 landed ...
             if constexpr (!(AA_X_ABLATE & 32)) block_barrier();  // ... everyone's did, and every wave holds its last fragments of tile kt
         }
-        if constexpr (HAS_NEXT2) prepare(kt + 2, kt & 1);        // stage kt&1 is free from here on
-        substep(IntTag<3>(), IntTag<0>(), st_next, HAS_NEXT, IntTag<0>(), IntTag<HAS_NEXT2 ? DP3 : 0>());
+        if constexpr (HAS_NEXT2) prep_scalars(kt + 2, kt & 1);   // stage kt&1 is free from here on; every piece of tile kt+1 is out: pb[] may change
+        substep(IntTag<3>(), IntTag<0>(), st_next, HAS_NEXT, IntTag<0>(), IntTag<HAS_NEXT2 ? DP3 : 0>(), BoolTag<HAS_NEXT2>());
     };
 
     auto put_bias = [&]() __attribute__((always_inline)) {       // the general epilogue path adds a bias slice from LDS: zeros here, the
@@ -339,13 +359,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             constexpr int NIF = decltype(nif_)::value;
             const char* st = smem + (s % RING) * STAGE_BYTES;
             const char* st_next = smem + ((s + 1) % RING) * STAGE_BYTES;
-            substep(IntTag<0>(), IntTag<1>(), st, true, IntTag<DPB>(), IntTag<HA ? DPA : 0>());
+            substep(IntTag<0>(), IntTag<1>(), st, true, IntTag<DPB>(), IntTag<HA ? DPA : 0>(), BoolTag<false>());
             if constexpr (HN) {
                 if constexpr (!(AA_X_ABLATE & 64)) dma_wait<PER_TILE * NIF>();      // my pieces of stage s+1 landed; younger stages stay in flight
                 if constexpr (!(AA_X_ABLATE & 32)) block_barrier();                 // everyone's did; every wave holds its last fragments of stage s
             }
-            if constexpr (HB) prepare(s + RING, s % RING);              // slot s % RING is free from here on
-            substep(IntTag<1>(), IntTag<0>(), st_next, HN, IntTag<0>(), IntTag<HB ? DPB : 0>());
+            if constexpr (HB) prep_scalars(s + RING, s % RING);         // slot s % RING is free from here on
+            substep(IntTag<1>(), IntTag<0>(), st_next, HN, IntTag<0>(), IntTag<HB ? DPB : 0>(), BoolTag<HB>());
         };
         if (nk > 0) {
             // stages 0 .. RING-2 in full, the first pieces of stage RING-1 (= the second sub-step of a "stage -1")

@@ -227,3 +227,14 @@ __device__ __forceinline__ void async_copy16_buf_s(const BufRsrc& r, unsigned la
     if constexpr ((AA_X_ABLATE & 1) != 0) { asm volatile("" :: "v"(lane_offset), "s"(uniform_offset)); return; }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r.v, (__attribute__((address_space(3))) void*)lds_wave_base, 16, lane_offset, uniform_offset, 0, 0);
 }
+
+// Source byte offset of one fed activation row for the prepared (tap, source) of an implicit-GEMM K step, branch-free:
+//   pb = pix * c2 + t          pix = pixel under tap (0, 0) (< 2^24), c2 = bytes per pixel, t = 16-byte slot + tap offset
+//   pb |= bit 31               when bit (31 - sh) of `invalid` is set (the tap reads padding / the row is behind the tile):
+//                              the buffer range check then deposits zeros
+// One asm statement = three VALU instructions where the source puts them (in an MFMA gap of conv_gemm_x.h).
+__device__ __forceinline__ void im2col_offset(unsigned& pb, unsigned pix, unsigned c2, unsigned t, unsigned sh, unsigned invalid) {
+    unsigned f;
+    asm volatile("v_mad_u32_u24 %0, %2, %3, %4\n\tv_lshlrev_b32 %1, %5, %6\n\tv_and_or_b32 %0, %1, %7, %0"
+                 : "=&v"(pb), "=&v"(f) : "v"(pix), "s"(c2), "v"(t), "s"(sh), "v"(invalid), "s"(0x80000000u));
+}

@@ -31,6 +31,7 @@ AUTOTUNE = True
 LAST_STAMPS = None
 GN_PLANS = None            # a list: groupnorm() appends (groups per workgroup, pieces per thread, parts, grid) or None per call
 MAX_OPERAND_BYTES = 1 << 31      # the contraction kernel's 32-bit operand offsets
+FORCE_TILE = -1       # tests / sweeps: >= 0 puts this tile-table index into AaConvGemm.tile of every conv_gemm call (strict: ineligible = error)
 K_SPLITS = 0          # tests: explicit K split count for calls that are not autotuned (0 = library decides)
 DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
 class _TileTable:
@@ -430,6 +431,8 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
         if choice is None and not aliased and not torch.cuda.is_current_stream_capturing():
             choice = _autotune(lib, d, _stream(x0), key, g.rows, x0.device)
         d.tile, d.k_splits = (-1, 0) if choice is None else choice
+    if FORCE_TILE >= 0:                                   # tests / sweeps: THIS tile or an error (aa_conv_gemm rejects a tile that
+        d.tile = FORCE_TILE                               # cannot carry out the call; the thread-local override merely prefers)
     ws = None
     need = lib.aa_conv_gemm_workspace(C.byref(d))        # split-K scratch for few-tile / long-K calls
     if DEBUG_ABLATE & 8:                                  # phase probe: [workgroup][8] shader-clock stamps

@@ -293,3 +293,7 @@ inline void async_copy16_buf_s(const BufRsrc& r, unsigned lane_offset, unsigned 
     if ((unsigned long long)lane_offset + 16 <= r.bytes) std::memcpy(dst, r.base + uniform_offset + lane_offset, 16);
     else std::memset(dst, 0, 16);
 }
+
+inline void im2col_offset(unsigned& pb, unsigned pix, unsigned c2, unsigned t, unsigned sh, unsigned invalid) {
+    pb = ((pix & 0xffffffu) * (c2 & 0xffffffu) + t) | ((invalid << sh) & 0x80000000u);
+}

@@ -402,11 +402,11 @@ def test_dma_tile_shapes(backend, cfg, N):
     g = ops.conv3x3_geom(n, h, w)
     res, temb = rnd(g.rows, N, seed=64), rnd(n, N, seed=65)
     lib = _lib.get()
-    lib.aa_set_tile_override(cfg)
+    ops.FORCE_TILE = cfg
     try:
         y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res, rowvec=temb, rowvec_div=h * w)
     finally:
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
     ref = nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1) + temb.float()[:, :, None, None]).half().float() + res.float()
     close(y, ref)
 
@@ -425,18 +425,21 @@ def test_geglu_wide_tiles(backend, D):
 def test_explicit_k_splits(backend, cfg, splits):
     """Caller-chosen K split count (autotuner): uneven K ranges, fp32 partials, reduce launch with the fused epilogue."""
     from animate_anything_amd import _lib
-    n, h, w, cin, N = 2, 9, 11, 128, 256              # K = 1152 = 18 (36) K steps: 18 / 5 leaves an uneven last range
+    n, h, w, cin = 2, 9, 11, 128                      # K = 1152 = 18 (36) K steps: 18 / 5 leaves an uneven last range
+    # (r04: with N = 256 for every case the 320-column tiles 39 / 42 / 49 never ran here - the forced index was ineligible and the
+    #  call silently took the automatic choice; ops.FORCE_TILE is strict now)
+    N = 320 if ops.TILE_TABLE[cfg][1] == 320 else 256
     x, wt, b = rnd(n, cin, h, w, seed=91), rnd(N, cin, 3, 3, scale=0.05, seed=92), rnd(N, seed=93)
     g = ops.conv3x3_geom(n, h, w)
     res = rnd(g.rows, N, seed=94)
     lib = _lib.get()
-    lib.aa_set_tile_override(cfg)
+    ops.FORCE_TILE = cfg
     ops.K_SPLITS = splits
     try:
         y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res, act=ops.AA_ACT_SILU)
     finally:
         ops.K_SPLITS = 0
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
     ref = nhwc(F.silu(F.conv2d(x.float(), wt.float(), b.float(), padding=1))).half().float() + res.float()
     close(y, ref)
 
@@ -448,11 +451,11 @@ def test_geglu_forced_tiles(backend, cfg):
     M, K, D = 300, 128, 384
     x, w, b = rnd(M, K, seed=95), rnd(2 * D, K, scale=0.1, seed=96), rnd(2 * D, seed=97)
     lib = _lib.get()
-    lib.aa_set_tile_override(cfg)
+    ops.FORCE_TILE = cfg
     try:
         y = ops.conv_gemm(x, ops.pack_weight(w, b, geglu=True), ops.linear_geom(M))
     finally:
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
     h = x.float() @ w.float().t() + b.float()
     close(y, h[:, :D] * F.gelu(h[:, D:]))
 
@@ -491,12 +494,12 @@ def test_sparse_last_round_is_split_to_small_tiles(backend, big):
     g = ops.conv3x3_geom(n, h, w)
     res = rnd(g.rows, N, seed=74)
     lib = _lib.get()
-    lib.aa_set_tile_override(big)
+    ops.FORCE_TILE = big
     ops.DEBUG_ABLATE = 4
     try:
         y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res)
     finally:
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
         ops.DEBUG_ABLATE = 0
     close(y, nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1)).half().float() + res.float())
 
@@ -511,12 +514,12 @@ def test_sparse_last_round_with_long_k_is_split_along_k(backend, cfg, N):
     g = ops.conv3x3_geom(n, h, w)
     res, temb = rnd(g.rows, N, seed=78), rnd(n, N, seed=79)
     lib = _lib.get()
-    lib.aa_set_tile_override(cfg)
+    ops.FORCE_TILE = cfg
     ops.DEBUG_ABLATE = 4
     try:
         y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res, rowvec=temb, rowvec_div=h * w, act=ops.AA_ACT_SILU)
     finally:
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
         ops.DEBUG_ABLATE = 0
     ref = nhwc(F.silu(F.conv2d(x.float(), wt.float(), b.float(), padding=1) + temb.float()[:, :, None, None])).half().float() + res.float()
     close(y, ref)
@@ -615,11 +618,11 @@ def test_conv3x3_halo_slab_kernel(backend, cfg, N, h, w, c0, c1):
     lib = _lib.get()
     pw = ops.pack_weight(wt, b)
     assert pw.k_order == 1
-    lib.aa_set_tile_override(cfg)
+    ops.FORCE_TILE = cfg
     try:
         y = ops.conv_gemm(x0, pw, g, x1=x1, residual=res, rowvec=temb, rowvec_div=h * w, act=AA_ACT_SILU)
     finally:
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
     ref = nhwc(F.silu(F.conv2d(x.float(), wt.float(), b.float(), padding=1) + temb.float()[:, :, None, None])).half().float() + res.float()
     close(y, ref)
 
@@ -653,11 +656,11 @@ def test_x_tiles_linear_every_loop_shape(backend, cfg, N, K):
     M = 300
     x, w, b, r = rnd(M, K, seed=201), rnd(N, K, scale=0.1, seed=202), rnd(N, seed=203), rnd(M, N, seed=204)
     lib = _lib.get()
-    lib.aa_set_tile_override(cfg)
+    ops.FORCE_TILE = cfg
     try:
         y = ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M), residual=r, act=ops.AA_ACT_SILU, out_scale=0.5)
     finally:
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
     close(y, (F.silu(x.float() @ w.float().t() + b.float()) + r.float()) * 0.5)
 
 
@@ -671,7 +674,7 @@ def test_x_tiles_per_row_bias_and_plain_forms(backend, cfg, N):
     brow, r, rv = rnd(M, seed=214), rnd(M, N, seed=215), rnd(3, N, seed=216)
     h = x.float() @ w.float().t()
     lib = _lib.get()
-    lib.aa_set_tile_override(cfg)
+    ops.FORCE_TILE = cfg
     try:
         close(ops.conv_gemm(x, ops.pack_weight(w, None), ops.linear_geom(M), bias=brow, bias_per_row=True), h + brow.float()[:, None])
         close(ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M)), h + b.float())
@@ -679,7 +682,7 @@ def test_x_tiles_per_row_bias_and_plain_forms(backend, cfg, N):
         close(ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M), residual=r, acc_scale=0.5, out_scale=2.0), ((h + b.float()) * 0.5 + r.float()) * 2.0)
         close(ops.conv_gemm(x, ops.pack_weight(w, None), ops.linear_geom(M), residual=r), h + r.float())
     finally:
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
 
 
 @pytest.mark.parametrize("cfg,N", X_TILES)
@@ -695,12 +698,12 @@ def test_x_tiles_temporal_conv_and_two_sources(backend, cfg, N):
     n, h, w_, c0, c1 = 2, 9, 13, 64, 128
     xa, xb = rnd(n, c0, h, w_, seed=214), rnd(n, c1, h, w_, seed=215)
     w2, b2 = rnd(N, c0 + c1, 3, 3, scale=0.05, seed=216), rnd(N, seed=217)
-    lib.aa_set_tile_override(cfg)
+    ops.FORCE_TILE = cfg
     try:
         y = ops.conv_gemm(tok, ops.pack_weight(wt, b), ops.tconv_geom(clips, frames, hw), residual=tok)
         y2 = ops.conv_gemm(nhwc(xa), ops.pack_weight(w2, b2), ops.conv3x3_geom(n, h, w_), x1=nhwc(xb))
     finally:
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
     ref = F.conv3d(x5.float(), wt.float(), b.float(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, c) + tok.float()
     close(y, ref)
     close(y2, nhwc(F.conv2d(torch.cat([xa, xb], 1).float(), w2.float(), b2.float(), padding=1)))
@@ -729,13 +732,13 @@ def test_x_tiles_short_and_odd_k_ranges(backend, cfg, N, K, splits):
     M = 270
     x, w, b = rnd(M, K, seed=231), rnd(N, K, scale=0.1, seed=232), rnd(N, seed=233)
     lib = _lib.get()
-    lib.aa_set_tile_override(cfg)
+    ops.FORCE_TILE = cfg
     ops.K_SPLITS = splits
     try:
         y = ops.conv_gemm(x, ops.pack_weight(w, b), ops.linear_geom(M))
     finally:
         ops.K_SPLITS = 0
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
     close(y, x.float() @ w.float().t() + b.float())
 
 
@@ -752,7 +755,7 @@ def test_x_tiles_bf16(backend, cfg, N):
     g = ops.conv3x3_geom(n, h, w)
     res = r(g.rows, N)
     lib = _lib.get()
-    lib.aa_set_tile_override(cfg)
+    ops.FORCE_TILE = cfg
     try:
         y = ops.conv_gemm(nhwc(x), ops.pack_weight(wt, b), g, residual=res)
         yg = None
@@ -761,7 +764,7 @@ def test_x_tiles_bf16(backend, cfg, N):
             xl, wl, bl = r(M, K), r(2 * D, K, scale=0.1), r(2 * D)
             yg = ops.conv_gemm(xl, ops.pack_weight(wl, bl, geglu=True), ops.linear_geom(M))
     finally:
-        lib.aa_set_tile_override(-1)
+        ops.FORCE_TILE = -1
     assert y.dtype == bf
     ref = nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1)).to(bf).float() + res.float()
     close(y, ref, tol=4e-2)                                   # bf16 storage: 8 mantissa bits
