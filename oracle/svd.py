@@ -497,11 +497,12 @@ def resize_with_antialiasing(x, size):
 
 def svd_pipeline(unet, vae, scheduler, image, image_embeddings, mask=None, num_frames=14, num_inference_steps=25,
                  min_guidance_scale=1.0, max_guidance_scale=3.0, fps=7, motion_bucket_id=127, noise_aug_strength=0.02,
-                 decode_chunk_size=None, latents=None, aug_noise=None, condition_latent=None, output_type="latent"):
+                 decode_chunk_size=None, latents=None, aug_noise=None, condition_latent=None, output_type="latent", callback=None):
     """/root/reference/models/pipeline.py:223-466 (mask given, 9-channel UNet) and :468-731 (TextStable...: `image_embeddings`
     supplied by the caller = CLIP image embedding and/or text embedding, CFG halves already concatenated, optional
     `condition_latent`).  `image` [B,3,H,W] in [-1,1] (already pre-processed); `aug_noise` / `latents` replace the
-    generator draws of the reference so the HIP pipeline can be driven with the same numbers."""
+    generator draws of the reference so the HIP pipeline can be driven with the same numbers; `callback(i, t, latents)` after
+    every step (tests/test_reference_pin.py compares with the reference's own `__call__` step by step)."""
     cfg = max_guidance_scale > 1.0
     b = image.shape[0]
     decode_chunk_size = decode_chunk_size or num_frames
@@ -527,7 +528,7 @@ def svd_pipeline(unet, vae, scheduler, image, image_embeddings, mask=None, num_f
         latents = torch.randn(b, num_frames, 4, h, w)
     latents = latents * scheduler.init_noise_sigma
     g = torch.linspace(min_guidance_scale, max_guidance_scale, num_frames).reshape(1, num_frames, 1, 1, 1).to(latents.dtype)
-    for t in scheduler.timesteps:
+    for i, t in enumerate(scheduler.timesteps):
         x = torch.cat([latents] * 2) if cfg else latents
         x = scheduler.scale_model_input(x, t)
         x = torch.cat([mask5, x, condition_latent], dim=2) if motion_mask else torch.cat([x, condition_latent], dim=2)
@@ -536,6 +537,8 @@ def svd_pipeline(unet, vae, scheduler, image, image_embeddings, mask=None, num_f
             vu, vc = v.chunk(2)
             v = vu + g * (vc - vu)
         latents = scheduler.step(v, t, latents).prev_sample
+        if callback is not None:
+            callback(i, t, latents)
     if output_type == "latent":
         return latents
     return decode_latents(vae, latents, num_frames, decode_chunk_size)

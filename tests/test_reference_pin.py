@@ -233,3 +233,186 @@ def test_latent_helpers_are_the_references():
     assert int(t[0]) == 501 and torch.equal(xs, x0.repeat(1, 1, 8, 1, 1))
     xo, tso = OP.ddpm_forward_timesteps(x0, 6, 8, s, noise=noise)
     assert list(tso) == list(ts) and torch.allclose(xo, xt, atol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------- SVD pipelines
+def _svd_parts(in_channels):
+    import oracle.svd as O
+    from util import svd_state
+    from test_svd import TINY_SVD_UNET, TINY_SVD_VAE
+    torch.manual_seed(0)
+    unet = O.UNetSpatioTemporalConditionModel(**dict(TINY_SVD_UNET, in_channels=in_channels)).eval()
+    unet.load_state_dict(svd_state(unet))
+    vae = O.AutoencoderKLTemporalDecoder(**TINY_SVD_VAE).eval()
+    vae.load_state_dict(svd_state(vae, 1))
+    return O, unet, vae
+
+
+def _svd_case(seed, b=1, f=3, H=16, W=24):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.rand(b, 3, H, W, generator=g) * 2 - 1
+    emb = torch.randn(b, 1, 64, generator=g)
+    latents = torch.randn(b, f, 4, H // 2, W // 2, generator=g)          # the tiny VAE scales by 2
+    mask = torch.zeros(1, H // 2, W // 2)
+    mask[:, 2:6, 3:9] = 1
+    return image, emb, latents, mask
+
+
+def _close(a, b, tol=1e-5):
+    return (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("guided", [True])
+def test_reference_mask_svd_pipeline_call_equals_oracle(ref_mod, guided):
+    """The reference's own `MaskStableVideoDiffusionPipeline.__call__` (models/pipeline.py:225-466: image-noise augmentation,
+    `repeat(mask, '1 h w -> 2 f 1 h w')`, `cat([mask, latent_model_input, image_latents], dim=2)` (:417-422), per-frame guidance
+    (:405-410, :435-440), the callback protocol) on the stub base class with oracle parts == `oracle.svd.svd_pipeline`,
+    latents after EVERY step.  (The reference hard-codes the guidance pair into the mask repeat: it has no unguided form.)"""
+    import models.pipeline as P
+    O, unet, vae = _svd_parts(9)
+    image, emb, latents, mask = _svd_case(21)
+    steps, frames, seed = 3, 3, 77
+    aug = torch.randn(image.shape, generator=torch.Generator().manual_seed(seed))
+    seen_o, seen_r = [], []
+    with torch.no_grad():
+        want = O.svd_pipeline(unet, vae, O.EulerDiscreteScheduler(), image, torch.cat([torch.zeros_like(emb), emb]), mask=mask,
+                              num_frames=frames, num_inference_steps=steps, latents=latents.clone(), aug_noise=aug,
+                              min_guidance_scale=1.0, max_guidance_scale=3.0, fps=7, motion_bucket_id=100, noise_aug_strength=0.05,
+                              callback=lambda i, t, l: seen_o.append(l.clone()))
+        pipe = P.MaskStableVideoDiffusionPipeline(vae, None, unet, O.EulerDiscreteScheduler())
+        pipe.image_embeddings = emb
+
+        def cb(p_, i, t, kw):
+            seen_r.append(kw["latents"].clone())
+            return {}
+        got = pipe(image, height=16, width=24, num_frames=frames, num_inference_steps=steps, latents=latents.clone(), mask=mask,
+                   generator=torch.Generator().manual_seed(seed), min_guidance_scale=1.0, max_guidance_scale=3.0, fps=7,
+                   motion_bucket_id=100, noise_aug_strength=0.05, output_type="latent", return_dict=False, callback_on_step_end=cb)
+    assert len(seen_o) == len(seen_r) == steps
+    for a, b in zip(seen_r, seen_o):
+        assert _close(a, b)
+    assert got.shape == want.shape == (1, frames, 4, 8, 12) and _close(got, want)
+    # ... and the decode helper of the stub is the oracle's: frames come back [B, 3, F, H, W]
+    assert pipe.decode_latents(got, frames, 2).shape == (1, 3, frames, 16, 24)
+
+
+@pytest.mark.parametrize("condition_type,in_channels,max_g", [("text", 8, 2.5), ("image", 9, 3.0), ("both", 9, 2.0), ("text", 9, 1.0)])
+def test_reference_text_svd_pipeline_call_equals_oracle(ref_mod, condition_type, in_channels, max_g):
+    """`TextStableVideoDiffusionPipeline.__call__` (models/pipeline.py:470-731): the three `condition_type` branches (:604-616),
+    `mask` doubled under guidance (:618-619), a caller-supplied `condition_latent` doubled (:647-649) or the VAE-encoded image,
+    8- and 9-channel UNets (:697-702), and the unguided form (max_guidance_scale = 1)."""
+    import models.pipeline as P
+    O, unet, vae = _svd_parts(in_channels)
+    image, emb, latents, mask = _svd_case(31)
+    steps, frames, seed = 2, 3, 5
+    cfg = max_g > 1.0
+    g = torch.Generator().manual_seed(13)
+    pe, ne = torch.randn(1, 5, 64, generator=g), torch.randn(1, 5, 64, generator=g)
+    cond = torch.randn(1, frames, 4, 8, 12, generator=g) if condition_type == "text" else None
+    img_e = torch.cat([torch.zeros_like(emb), emb]) if cfg else emb
+    txt_e = torch.cat([ne, pe]) if cfg else pe
+    ctx = {"text": txt_e, "image": img_e, "both": torch.cat([img_e, txt_e], dim=1)}[condition_type]
+    aug = torch.randn(image.shape, generator=torch.Generator().manual_seed(seed))
+    seen_o, seen_r = [], []
+    with torch.no_grad():
+        want = O.svd_pipeline(unet, vae, O.EulerDiscreteScheduler(), image, ctx, mask=mask if in_channels == 9 else None,
+                              num_frames=frames, num_inference_steps=steps, latents=latents.clone(), aug_noise=aug,
+                              condition_latent=cond, min_guidance_scale=1.0 if cfg else 1.0, max_guidance_scale=max_g,
+                              callback=lambda i, t, l: seen_o.append(l.clone()))
+        pipe = P.TextStableVideoDiffusionPipeline(vae, None, unet, O.EulerDiscreteScheduler())
+        pipe.image_embeddings = emb
+        mask5 = mask.reshape(1, 1, 1, *mask.shape[-2:]).repeat(1, frames, 1, 1, 1)          # [b, f, 1, h, w] (train_svd.py eval)
+
+        def cb(p_, i, t, kw):
+            seen_r.append(kw["latents"].clone())
+            return {}
+        got = pipe(image, prompt_embeds=pe, negative_prompt_embeds=ne, height=16, width=24, num_frames=frames,
+                   num_inference_steps=steps, latents=latents.clone(), condition_type=condition_type, condition_latent=cond,
+                   mask=mask5, generator=torch.Generator().manual_seed(seed), min_guidance_scale=1.0, max_guidance_scale=max_g,
+                   output_type="latent", return_dict=False, callback_on_step_end=cb)
+    assert len(seen_o) == len(seen_r) == steps
+    for a, b in zip(seen_r, seen_o):
+        assert _close(a, b)
+    assert _close(got, want)
+
+
+# --------------------------------------------------------------------------------------------- layerdiffuse RGBA add-ons (row f3)
+def test_reference_unet384_forward_equals_oracle(ref_mod):
+    """The reference's own `UNet384` (models/layerdiffuse_VAE.py:44-177: constructor channel arithmetic through
+    `get_down_block` / `UNetMidBlock2D` / `get_up_block`, `latent_conv_in` added in front of the fourth down block :156-157, the
+    residual-tuple bookkeeping of its forward :160-169) built on the stub 2-D blocks == `oracle.layerdiffuse.UNet384` on one state
+    dict (identical key sets), default architecture, two image sizes."""
+    import models.layerdiffuse_VAE as LV
+    from oracle import layerdiffuse as OL
+    assert LV.__file__.startswith(REF)
+    torch.manual_seed(0)
+    ref = LV.UNet384().eval()
+    orc = OL.UNet384().eval()
+    state = seeded_state(orc, rezero_std=0.05)                   # the zero-initialised latent_conv_in is re-drawn: the injection counts
+    assert sorted(ref.state_dict().keys()) == sorted(state.keys())
+    ref.load_state_dict(state, strict=True)
+    orc.load_state_dict(state)
+    g = torch.Generator().manual_seed(3)
+    for (h, w) in ((32, 48), (64, 64)):
+        x = torch.rand(2, 3, h, w, generator=g) * 2 - 1
+        lat = torch.randn(2, 4, h // 8, w // 8, generator=g)
+        with torch.no_grad():
+            a, b = ref(x, lat), orc(x, lat)
+            a0 = ref(x, torch.zeros_like(lat))
+        assert a.shape == b.shape == (2, 4, h, w)
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+        assert (a - a0).abs().max().item() > 1e-4               # the latent really enters
+
+
+def test_reference_stage2_pipeline_call_equals_oracle(ref_mod):
+    """`MaskedLatentToVideoPipeline.__call__` (models/pipeline_stage2.py:173-337): guidance order `cat([prompt_embeds[1],
+    prompt_embeds[0]])` over `encode_prompt`'s (positive, negative) pair (:229-231), the loop (the same body as
+    LatentToVideoPipeline's), and the alpha decode (:290-318: VAE frames + latents -> `vae_alpha_decoder` -> thresholded alpha,
+    (fg + 1) * 127.5, uint8 RGBA) == the oracle loop + `oracle.layerdiffuse.decode_rgba`."""
+    import oracle
+    import types
+    absent = [m for m in ("torchvision", "torchvision.transforms") if m not in sys.modules]      # (imported at the top of the file, unused by this class)
+    for m in absent:
+        sys.modules[m] = types.ModuleType(m)
+    try:
+        import models.pipeline_stage2 as P2
+    finally:
+        for m in absent:
+            del sys.modules[m]
+    from oracle import layerdiffuse as OL
+    from util import TINY_VAE
+    assert P2.__file__.startswith(REF)
+    torch.manual_seed(0)
+    unet = oracle.UNet3DConditionModel(**TINY_UNET).eval()
+    unet.load_state_dict(seeded_state(unet))
+    vae = oracle.AutoencoderKL(**dict(TINY_VAE, block_out_channels=(32, 32, 32, 32))).eval()       # x8, like the real VAE: the alpha decoder
+    vae.load_state_dict(seeded_state(vae, 1))                                                       # takes the latent at 1/8 of the frame
+    dec = OL.UNet384(block_out_channels=(8, 16, 32, 32), layers_per_block=1, attention_head_dim=8).eval()
+    dec.load_state_dict(seeded_state(dec, 2, rezero_std=0.05))
+    g = torch.Generator().manual_seed(9)
+    r = lambda *s: torch.randn(*s, generator=g)
+    frames, h, w, steps = 2, 4, 6, 3
+    x0, noise, pos, neg = r(1, 4, 1, h, w) * 0.5, r(1, 4, frames, h, w), r(1, 7, 64), r(1, 7, 64)
+    mask = torch.zeros(1, 1, 1, h, w)
+    mask[..., 1:3, 2:5] = 1
+    osched = oracle.DPMSolverMultistepScheduler()
+    osched.set_timesteps(steps)
+    init = oracle.ddpm_add_noise(x0.repeat(1, 1, frames, 1, 1), noise, int(osched.timesteps[0]))
+    with torch.no_grad():
+        opipe = oracle.LatentToVideoPipeline(vae, unet, osched)
+        video_o, lat_o = opipe(latents=init, prompt_embeds=pos, negative_prompt_embeds=neg, condition_latent=x0, mask=mask, motion=[4.0],
+                               num_inference_steps=steps, guidance_scale=9.0, return_dict=False, output_type="pt")
+        png_o, alpha_o, rgb_o = OL.decode_rgba(video_o, lat_o, dec)
+        ref_pipe = P2.MaskedLatentToVideoPipeline(vae, None, None, unet, _SchedulerAdapter())
+        # diffusers 0.24 `encode_prompt` returns the (positive, negative) pair un-concatenated; the reference re-orders it itself
+        ref_pipe.encode_prompt = lambda prompt, device, n, cfg, negative_prompt=None, prompt_embeds=None, negative_prompt_embeds=None, lora_scale=None: (prompt_embeds, negative_prompt_embeds)
+        video_r, lat_r, png_r, alpha_r, rgb_r = ref_pipe(
+            vae_alpha_decoder=dec, height=h * 8, width=w * 8, latents=init, prompt_embeds=pos, negative_prompt_embeds=neg, condition_latent=x0,
+            mask=mask, motion=[4.0], num_inference_steps=steps, guidance_scale=9.0, return_dict=False, output_type="pt")
+    assert (lat_r - lat_o).abs().max().item() <= 1e-5 * max(1.0, lat_o.abs().max().item())
+    assert (video_r - video_o).abs().max().item() <= 1e-5
+    assert png_r.shape == png_o.shape == (frames, h * 8, w * 8, 4) and png_r.dtype == png_o.dtype
+    # uint8 after a threshold: allow the odd pixel whose pre-rounding value sits on an integer boundary to differ by one count
+    diff = (png_r.astype(int) - png_o.astype(int))
+    assert (abs(diff[..., :3]) <= 1).all() and (diff[..., :3] != 0).mean() < 1e-3
+    assert (alpha_r == alpha_o).mean() > 0.999 and (rgb_r.astype(int) - rgb_o.astype(int)).__abs__().max() <= 1
