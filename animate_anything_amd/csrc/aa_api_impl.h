@@ -121,6 +121,14 @@ static bool cg_slab_ok(const AaConvGemm& d, const CgCfg& c) {
 static thread_local unsigned g_x_disabled = 0;   // bit i: table entry 36 + i is not offered (aa_set_tile_override(-100 - mask): bisecting aid)
 static bool cg_x_ok(const AaConvGemm& d) {
     if (!(d.h_virt == d.h_in && d.w_virt == d.w_in)) return false;
+    {   // their K walk is (64-channel chunk, tap, channel); one validity bit per tap in a 32-bit mask; source offsets are
+        // pixel * bytes-per-pixel through v_mad_u32_u24, counted from pad_h rows + pad_w pixels in front of the tensor, bit 31 = "zero"
+        const int taps = d.kh * d.kw;
+        if (taps > 1 && d.k_order != 1) return false;
+        if (taps > 31) return false;
+        const int64_t px = (int64_t)d.n_img * d.h_in * d.w_in + (int64_t)d.pad_h * d.w_in + d.pad_w + (int64_t)d.kh * d.w_in + d.kw;
+        if (px >= ((int64_t)1 << 24) || px * (d.c0 > d.c1 ? d.c0 : d.c1) * 2 >= ((int64_t)1 << 31)) return false;
+    }
     if (d.rowvec) {          // their epilogue reads the row vector through a buffer descriptor: 32-bit byte offsets below 2^31
         const int64_t M = (int64_t)d.n_img * d.h_out * d.w_out;
         const int64_t ld = d.rowvec_ld ? d.rowvec_ld : d.n_out;
@@ -171,7 +179,9 @@ static bool cg_dma_ok(const AaConvGemm& d) {
            d.n_out % 8 == 0 && (!d.bias || d.bias_per_row || aligned16(d.bias)) && (!d.rowvec || aligned16(d.rowvec)) &&
            // operands are addressed with 32-bit byte offsets through buffer descriptors; offsets >= 2^31 mean "zero"
            (int64_t)d.n_img * d.h_in * d.w_in * (d.c0 > d.c1 ? d.c0 : d.c1) * 2 < ((int64_t)1 << 31) &&
-           (int64_t)d.n_pad * d.k_pad * 2 < ((int64_t)1 << 31);
+           (int64_t)d.n_pad * d.k_pad * 2 < ((int64_t)1 << 31) &&
+           // a scattered output grid (out_sy / out_sx) is addressed through one descriptor over the whole grid
+           (!cgd_out_mapped(d) || (int64_t)d.n_img * d.h_out * d.w_out * (d.out_sy > 1 ? d.out_sy : 1) * (d.out_sx > 1 ? d.out_sx : 1) * d.ldo * 2 < ((int64_t)1 << 31));
 }
 
 // How one aa_conv_gemm call is carried out on the LDS-DMA path (shared by aa_conv_gemm_workspace and the launcher).
@@ -553,6 +563,9 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream) {
     if (!aligned16(d->a0) || !aligned16(d->a1) || !aligned16(d->w)) return fail(AA_E_ALIGN, "conv_gemm: operands must be 16-byte aligned");
     if (d->out_dtype != AA_F32 && d->out_dtype != d->dtype) return fail(AA_E_DTYPE, "conv_gemm: out_dtype must be dtype or f32");
     if (d->act != AA_ACT_NONE && d->act != AA_ACT_SILU) return fail(AA_E_SHAPE, "conv_gemm: activation %d is not fused here (AA_ACT_NONE / AA_ACT_SILU)", d->act);
+    if (d->out_sy < 0 || d->out_sx < 0 || d->out_oy < 0 || d->out_ox < 0 || d->out_oy >= (d->out_sy > 1 ? d->out_sy : 1) || d->out_ox >= (d->out_sx > 1 ? d->out_sx : 1))
+        return fail(AA_E_SHAPE, "conv_gemm: bad output grid mapping (out_sy=%d out_sx=%d out_oy=%d out_ox=%d)", d->out_sy, d->out_sx, d->out_oy, d->out_ox);
+    if (cgd_out_mapped(*d) && !cg_dma_ok(*d)) return fail(AA_E_SHAPE, "conv_gemm: a scattered output grid needs the LDS-DMA path (channels %% 64, 16-byte rows, < 2 GiB)");
     // a tile named in the descriptor is a demand, not a hint: a call it cannot carry out fails (it used to fall through to the
     // automatic choice, so a "forced tile" test could pass without running that tile).  The thread-local override of
     // aa_set_tile_override stays a preference ("every following call whose packed width it divides").

@@ -42,16 +42,46 @@ __host__ __device__ inline int cgd_lds_bytes(int bm, int bn, int bk, int stages)
 // wave runs straight through MI x NI blocks; GELU on packed fp32 pairs.  BIAS = false: the caller started the
 // accumulators from the bias.  Everything else (SiLU, per-row bias, GEGLU with a residual ...) takes cgd_epilogue_g's
 // general path below.
-template <typename T, int MI, int NI, bool GEGLU, bool RV, bool POST, bool BIAS, typename Get>
-__device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW) {
+// Output row of GEMM row m: m itself, or - AaConvGemm.out_sy / out_sx > 1 - pixel (y * out_sy + out_oy, x * out_sx + out_ox) of an
+// [n_img, h_out * out_sy, w_out * out_sx] grid (one parity class of the four 2x2 convolutions that carry out Upsample2D).
+__host__ __device__ __forceinline__ bool cgd_out_mapped(const AaConvGemm& p) { return p.out_sy > 1 || p.out_sx > 1; }
+__host__ __device__ __forceinline__ int64_t cgd_out_row(const AaConvGemm& p, const int m) {
+    if (!cgd_out_mapped(p)) return m;
+    const int sy = p.out_sy > 1 ? p.out_sy : 1, sx = p.out_sx > 1 ? p.out_sx : 1;
+    const int x = m % p.w_out, t = m / p.w_out, y = t % p.h_out, img = t / p.h_out;
+    return ((int64_t)img * (p.h_out * sy) + (y * sy + p.out_oy)) * (p.w_out * sx) + (x * sx + p.out_ox);
+}
+
+// LayerNorm folded into the consuming contraction (AaConvGemm.ln_stats): scale and offset of GEMM row m from the partial
+// (sum, sum of squares) pairs its producer left:  LN(x) W^T = a * (x W'^T) + nm * colsum(W') + b',  a = rstd, nm = -mean * rstd.
+struct LnRow { float a, nm; };
+__device__ __forceinline__ LnRow cgd_ln_row(const AaConvGemm& p, const int m) {
+    const float* st = p.ln_stats + (int64_t)m * p.ln_parts * 2;
+    float s = 0.0f, q = 0.0f;
+    for (int t = 0; t < p.ln_parts; ++t) { s += st[2 * t]; q += st[2 * t + 1]; }
+    const float inv_c = 1.0f / (float)(p.c0 + p.c1);
+    const float mean = s * inv_c;
+    const float var = fmaxf(q * inv_c - mean * mean, 0.0f);
+    const float rstd = rsqrtf(var + p.ln_eps);
+    return LnRow{rstd, -mean * rstd};
+}
+
+template <typename T, int MI, int NI, bool GEGLU, bool RV, bool POST, bool BIAS, bool LNF, bool STATS, typename Get>
+__device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW, const int part,
+                                                  const float* sLn, const int ln_w) {
+    // sLn: LDS copy of colsum(W') [ln_w] and b' [ln_w] of this WAVE's columns (nullptr: read AaConvGemm.ln_cols), LNF only
     static_assert(!GEGLU || (NI % 2 == 0 && !RV && !POST), "GEGLU pairs value block j with gate block j + 1");
+    static_assert(!LNF || (!RV && !POST && !BIAS && !STATS), "the LayerNorm fold covers the plain and the GEGLU form");
+    static_assert(!STATS || !GEGLU, "row statistics: plain / residual forms");
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NJ = GEGLU ? NI / 2 : NI;                 // output blocks per block row
     const int lane = threadIdx.x & 63;
     const int ec = lane & 31, eh = lane >> 5;
     const int n_cols = GEGLU ? (p.n_out >> 1) : p.n_out;
     const int rows_ok = max(0, min(MI * 32, M - m_wave));
-    const BufRsrc r_out = make_rsrc(reinterpret_cast<const T*>(p.out) + (int64_t)m_wave * p.ldo, (unsigned)(rows_ok * p.ldo) * 2u);
+    const bool mapped = cgd_out_mapped(p);                  // rows scatter over a bigger output grid: whole-tensor descriptor, absolute rows
+    const BufRsrc r_out = mapped ? make_rsrc(p.out, (unsigned)((int64_t)p.n_img * p.h_out * p.w_out * (p.out_sy > 1 ? p.out_sy : 1) * (p.out_sx > 1 ? p.out_sx : 1) * p.ldo * 2))
+                                 : make_rsrc(reinterpret_cast<const T*>(p.out) + (int64_t)m_wave * p.ldo, (unsigned)(rows_ok * p.ldo) * 2u);
     const T* resid = reinterpret_cast<const T*>(p.residual);
     const BufRsrc r_res = make_rsrc(resid ? resid + (int64_t)m_wave * p.ldr : resid, resid ? (unsigned)(rows_ok * p.ldr) * 2u : 0u);
     const BufRsrc r_rv = make_rsrc(p.rowvec, 0x7fffffffu);
@@ -88,10 +118,28 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
         }
     };
     prefetch(IntTag<0>());
+    // LayerNorm fold: scale / offset of this lane's row of every block row; colsum(W') and b' of the wave's columns sit in LDS
+    // (sLn: [2][columns of the wave], fp32) or, for callers without an LDS copy, are read from AaConvGemm.ln_cols
+    LnRow lnr[LNF ? MI : 1];
+    if constexpr (LNF) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) lnr[i] = cgd_ln_row(p, min(m_wave + i * 32 + ec, M - 1));
+    }
+    // row statistics of the STORED values (sum, sum of squares over this wave's columns) on the idle matrix pipe: with the two
+    // 16-byte output packs of a block as the B operand, a ones fragment as A gives the row sums in every accumulator row, the
+    // pack itself as A the Gram matrix whose diagonal is the sum of squares (products of 16-bit values are exact in fp32)
+    u32x4 ones_frag;
+    if constexpr (STATS) { Pack8<T> o1; for (int e = 0; e < 8; ++e) o1.e[e] = (T)1.0f; ones_frag = o1.raw; }
     static_for<MI>([&](auto i_) __attribute__((always_inline)) {
         constexpr int i = decltype(i_)::value;
         const unsigned row = (unsigned)(i * 32 + ec);
-        const unsigned o_row = row * (unsigned)p.ldo * 2u;
+        f32x16 st_sum, st_sq;
+        if constexpr (STATS) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st_sum[e] = 0.0f; st_sq[e] = 0.0f; }
+        }
+        const unsigned o_row = !mapped ? row * (unsigned)p.ldo * 2u
+                                       : ((int)row < rows_ok ? (unsigned)(cgd_out_row(p, m_wave + (int)row) * p.ldo) * 2u : OOB);
         if constexpr (i + 1 < MI) prefetch(IntTag<i + 1>());
         static_for<NJ>([&](auto h_) __attribute__((always_inline)) {
             constexpr int h = decltype(h_)::value, j = GEGLU ? 2 * h : h;
@@ -117,6 +165,18 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
                     for (int e = 0; e < 8; ++e) v[8 * q + e] += (float)r.e[e];
                 }
             }
+            auto ln_apply = [&](float (&x)[16], const int jj) __attribute__((always_inline)) {       // x = a * x + nm * colsum + b'
+                const int cw = jj * 32 + 16 * eh;                       // first of this lane's 16 columns, counted from n_wave
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 cs, bb;
+                    if (sLn) { cs = *reinterpret_cast<const f32x4*>(sLn + cw + 4 * q4); bb = *reinterpret_cast<const f32x4*>(sLn + ln_w + cw + 4 * q4); }
+                    else { cs = *reinterpret_cast<const f32x4*>(p.ln_cols + n_wave + cw + 4 * q4); bb = *reinterpret_cast<const f32x4*>(p.ln_cols + p.n_pad + n_wave + cw + 4 * q4); }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[4 * q4 + e] = fmaf(x[4 * q4 + e], lnr[i].a, fmaf(lnr[i].nm, cs[e], bb[e]));
+                }
+            };
+            if constexpr (LNF) ln_apply(v, j);
             if constexpr (GEGLU) {
                 float g[16];
                 {
@@ -124,6 +184,7 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
 #pragma unroll
                     for (int e = 0; e < 16; ++e) g[e] = a[e];
                 }
+                if constexpr (LNF) ln_apply(g, j + 1);
                 if constexpr (BIAS) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -154,14 +215,35 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
                 for (int e = 0; e < 8; ++e) o.e[e] = (T)v[8 * q + e];
                 if constexpr ((AA_X_ABLATE & 16) != 0) { if (o.raw[0] == 0x12345678u) buf_store16(r_out, o_row + coff[h][q], o.raw); }   // (ablation build: no stores)
                 else buf_store16(r_out, o_row + coff[h][q], o.raw);
+                if constexpr (STATS) {
+                    st_sum = mfma_32x32x16(T(), ones_frag, o.raw, st_sum);
+                    st_sq = mfma_32x32x16(T(), o.raw, o.raw, st_sq);
+                }
             }
         });
+        if constexpr (STATS) {
+            // row m = lane & 31: its sum sits in every accumulator row; the diagonal element (m, m) of the Gram matrix in register
+            // (m & 3) + 4 * (m >> 3) of the half-wave (m >> 2) & 1
+            const int idx = (ec & 3) + 4 * (ec >> 3);
+            float sq = st_sq[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) sq = idx == e ? st_sq[e] : sq;
+            const int m = m_wave + (int)row;
+            if (eh == ((ec >> 2) & 1) && m < M) {
+                float* dst = p.row_stats + ((int64_t)m * p.row_stats_parts + part) * 2;
+                dst[0] = st_sum[0];
+                dst[1] = sq;
+            }
+        }
     });
 }
 
 // BIAS_FOLDED: the accumulators were started from the bias (conv_gemm_x.h) and sBiasW holds zeros.
+// part / sLn / ln_w: this wave's slot of AaConvGemm.row_stats (-1: the caller cannot emit them) and its LDS copy of the LayerNorm
+// fold's column vectors (cgd_epilogue_fast).
 template <typename T, int MI, int NI, bool BIAS_FOLDED = false, typename Get>
-__device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW) {
+__device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW,
+                                               const int part = -1, const float* sLn = nullptr, const int ln_w = 0) {
     // get(IntTag<i>, IntTag<j>) -> the 16 accumulators of 32x32 block (i, j) of this lane (an array element, or a read-out
     // of the literal accumulation registers of conv_gemm_x.h)
     const int lane = threadIdx.x & 63;
@@ -175,18 +257,28 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
     const bool post = resid || p.out_scale != 1.0f || acc_scale != 1.0f;
     const bool silu = p.act == AA_ACT_SILU;
     const bool pre_is_rv = rowvec != nullptr;             // the prefetch registers carry the row vector, else the residual
+    const bool lnf = p.ln_stats != nullptr;               // LayerNorm folded into this contraction (host: no bias / row vector / residual with it)
+    const bool stats = p.row_stats != nullptr && part >= 0;
     // the combinations that carry the step take the branch-free forms - where the accumulators sit in the accumulation registers
     // (conv_gemm_x.h): next to 128-160 accumulators in VGPRs the extra offsets spill (measured: 160-220 dwords of scratch)
     if (BIAS_FOLDED && !silu && !p.bias_per_row) {
-        if (p.geglu) {
-            if constexpr (NI % 2 == 0) { if (!rowvec && !post) { cgd_epilogue_fast<T, MI, NI, true, false, false, !BIAS_FOLDED>(p, M, get, m_wave, n_wave, sBiasW); return; } }
+        if (lnf) {
+            if (p.geglu) {
+                if constexpr (NI % 2 == 0) { cgd_epilogue_fast<T, MI, NI, true, false, false, false, true, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w); return; }
+            } else { cgd_epilogue_fast<T, MI, NI, false, false, false, false, true, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w); return; }
+        } else if (p.geglu) {
+            if constexpr (NI % 2 == 0) { if (!rowvec && !post) { cgd_epilogue_fast<T, MI, NI, true, false, false, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w); return; } }
         } else if (rowvec) {
-            if (post) cgd_epilogue_fast<T, MI, NI, false, true, true, !BIAS_FOLDED>(p, M, get, m_wave, n_wave, sBiasW);
-            else cgd_epilogue_fast<T, MI, NI, false, true, false, !BIAS_FOLDED>(p, M, get, m_wave, n_wave, sBiasW);
+            if (post) cgd_epilogue_fast<T, MI, NI, false, true, true, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
+            else cgd_epilogue_fast<T, MI, NI, false, true, false, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
+            return;
+        } else if (stats) {
+            if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED, false, true>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
+            else cgd_epilogue_fast<T, MI, NI, false, false, false, !BIAS_FOLDED, false, true>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
             return;
         } else {
-            if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED>(p, M, get, m_wave, n_wave, sBiasW);
-            else cgd_epilogue_fast<T, MI, NI, false, false, false, !BIAS_FOLDED>(p, M, get, m_wave, n_wave, sBiasW);
+            if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
+            else cgd_epilogue_fast<T, MI, NI, false, false, false, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
             return;
         }
     }
@@ -200,6 +292,8 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
         const float brow = (p.bias_per_row && bias) ? (float)bias[mc] : 0.0f;
         const T* rv = rowvec ? rowvec + (int64_t)(mc / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out) : nullptr;
         const T* rs = resid ? resid + (int64_t)mc * p.ldr : nullptr;
+        const int64_t o_row_g = cgd_out_row(p, mc) * p.ldo;
+        const LnRow lr = lnf ? cgd_ln_row(p, mc) : LnRow{1.0f, 0.0f};
         // one block-row of row-vector (or residual) pieces is fetched up front so their latency overlaps
         u32x4 pre[NI][2];
 #pragma unroll
@@ -225,7 +319,7 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
                 Pack8<T> o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o.e[e] = (T)v[q][e];
-                if ((AA_X_ABLATE & 16) ? (o.raw[0] == 0x12345678u && m_ok) : (m_ok && nc + 8 * q + 8 <= n_cols)) *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + nc + 8 * q) = o.raw;   // (ablation build: no stores)
+                if ((AA_X_ABLATE & 16) ? (o.raw[0] == 0x12345678u && m_ok) : (m_ok && nc + 8 * q + 8 <= n_cols)) *reinterpret_cast<u32x4*>(out + o_row_g + nc + 8 * q) = o.raw;   // (ablation build: no stores)
             }
         };
         auto block_f32 = [&](auto j_, float (&v)[2][8]) __attribute__((always_inline)) {     // accumulators + bias (+ row vector) (+ SiLU) in fp32
@@ -239,6 +333,11 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
                 if (pre_is_rv) r.raw = pv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[q][e] = a[8 * q + e] + (float)b.e[e] + brow;
+                if (lnf) {                                // rstd * acc - rstd * mean * colsum(W') + b'  (general path: the vectors come from memory)
+                    const float* cs = p.ln_cols + n_wave + j * 32 + 16 * eh + 8 * q;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[q][e] = fmaf(v[q][e], lr.a, fmaf(lr.nm, cs[e], cs[p.n_pad + e]));
+                }
                 if (pre_is_rv) {                          // uniform branches once per eight values, not once per value
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[q][e] += (float)r.e[e];
@@ -700,6 +799,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const AaConvGemm p, 
             for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
         }
         // uniform branches once per eight values (not once per value)
+        if (p.ln_stats) {
+            const LnRow lr = cgd_ln_row(p, m);
+            const float* cs = p.ln_cols + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], lr.a, fmaf(lr.nm, cs[e], cs[p.n_pad + e]));
+        }
         if (bias) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)bias[p.bias_per_row ? m : n + e];
@@ -724,7 +829,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const AaConvGemm p, 
         Pack8<T> o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.e[e] = (T)(v[e] * p.out_scale);
-        *reinterpret_cast<u32x4*>(out + (int64_t)m * p.ldo + n) = o.raw;
+        *reinterpret_cast<u32x4*>(out + cgd_out_row(p, m) * p.ldo + n) = o.raw;
     }
 }
 }  // namespace aa

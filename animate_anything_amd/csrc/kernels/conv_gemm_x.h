@@ -160,14 +160,20 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const unsigned wb_step = (unsigned)(NW * RPI * p.k_pad) * 2u;
     const int taps = kh_ * kw_;
 
-    // K position of the next prepare() call (wave-uniform scalars, advanced incrementally; see conv_gemm_dma.h)
-    int n_tap, n_dy, n_dx, n_cb;
+    // K position of the next prepare() call (wave-uniform scalars, advanced incrementally): filter tap, its column, the tap's pixel
+    // offset from tap (0, 0), channel base.  The packed K axis is walked as (64-channel chunk, tap, channel) - AaConvGemm.k_order 1,
+    // which for one tap is k_order 0 as well (the host offers these tiles to nothing else: cg_x_ok).
+    int n_tap, n_dx, n_toff, n_cb;
     {
         const int k0 = kbase * BK;
-        if (p.k_order) { const int unit = k0 >> 6; const int chunk = unit / taps; n_tap = unit - chunk * taps; n_cb = chunk * 64 + (k0 & 63); }
-        else           { n_tap = k0 / ctot; n_cb = k0 - n_tap * ctot; }
-        n_dy = n_tap / kw_; n_dx = n_tap - n_dy * kw_;
+        const int unit = k0 >> 6, chunk = unit / taps;
+        n_tap = unit - chunk * taps;
+        n_cb = chunk * 64 + (k0 & 63);
+        const int dy = n_tap / kw_;
+        n_dx = n_tap - dy * kw_;
+        n_toff = dy * p.w_in + n_dx;
     }
+    const int wrap_d = p.w_in - kw_ + 1;                    // pixel offset from the last tap of a filter row to the first of the next
     int cur_src = -1;
     unsigned pb[AJ];                     // byte offset of each fed row's source pixel for the prepared (tap, source) (bit 31 = halo / tail)
     bool is_src1 = false;
@@ -181,30 +187,26 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     };
     // wave-uniform part of prepare(): advances the K position, leaves what the DMA pieces of tile kt need besides pb[]
     auto prep_scalars = [&](int kt, int buf) __attribute__((always_inline)) {
-        const int tap = n_tap, cb = n_cb, dy = n_dy, dx = n_dx;
+        const int tap = n_tap, cb = n_cb, toff = n_toff;
         {
+            const bool last_tap = n_tap + 1 == taps;
             const bool wrap_x = n_dx + 1 == kw_;
-            if (p.k_order) {
-                const bool half = BK == 32 && !(n_cb & 32);              // first half of a 64-channel unit: same tap
-                const bool last_tap = n_tap + 1 == taps;
-                const int cb_unit = (n_cb & ~63) + (last_tap ? 64 : 0);
-                const int t1 = last_tap ? 0 : n_tap + 1;
-                const int y1 = last_tap ? 0 : (wrap_x ? n_dy + 1 : n_dy);
-                const int x1 = (last_tap || wrap_x) ? 0 : n_dx + 1;
-                n_cb = half ? n_cb + 32 : cb_unit;
-                n_tap = half ? n_tap : t1; n_dy = half ? n_dy : y1; n_dx = half ? n_dx : x1;
+            const int t1 = last_tap ? 0 : n_tap + 1;
+            const int o1 = last_tap ? 0 : n_toff + (wrap_x ? wrap_d : 1);
+            const int x1 = (last_tap || wrap_x) ? 0 : n_dx + 1;
+            if constexpr (BK == 32) {
+                const bool stay = !(n_cb & 32);                          // first half of a 64-channel unit: same tap
+                n_cb = stay ? n_cb + 32 : (n_cb & ~63) + (last_tap ? 64 : 0);
+                n_tap = stay ? n_tap : t1; n_toff = stay ? n_toff : o1; n_dx = stay ? n_dx : x1;
             } else {
-                const bool last_c = n_cb + BK >= ctot;
-                n_cb = last_c ? 0 : n_cb + BK;
-                n_tap = last_c ? n_tap + 1 : n_tap;
-                n_dy = (last_c && wrap_x) ? n_dy + 1 : n_dy;
-                n_dx = last_c ? (wrap_x ? 0 : n_dx + 1) : n_dx;
+                n_cb += last_tap ? 64 : 0;
+                n_tap = t1; n_toff = o1; n_dx = x1;
             }
         }
         is_src1 = cb >= p.c0;
         s_c2 = (unsigned)(is_src1 ? p.c1 : p.c0) * 2u;
         s_sh = (unsigned)(31 - min(tap, 31));                          // taps past the filter (K padding) hit a set bit: zeros
-        v_t = slot16 + (unsigned)(dy * p.w_in + dx) * s_c2;
+        v_t = slot16 + (unsigned)toff * s_c2;
         is_ccb = (unsigned)(is_src1 ? cb - p.c0 : cb) * 2u;
         is_kb = (unsigned)((kbase + kt) * BK) * 2u;
         is_buf = buf;

@@ -70,6 +70,9 @@ class _Packed:
         return self._pw
 
 
+UPSAMPLE_AS_PARITY_CONVS = True      # Upsample2D at exactly x2: four 2x2 convolutions (ops.pack_upsample2x_weights); False = the 3x3 gather form
+
+
 def _no_eager(name):
     raise RuntimeError(f"{name}: this module only runs through the HIP token path of animate_anything_amd")
 
@@ -217,8 +220,30 @@ class Upsample2D(nn.Module):
         super().__init__()
         self.conv = Conv2d(channels, out_channels or channels, 3, padding=1)
 
+    def parity_packed(self):
+        """The four 2x2 filters of the exact x2 form (ops.pack_upsample2x_weights), cached like Conv2d.packed()."""
+        key = weights_key(self.conv.weight, self.conv.bias)
+        if self._pp is None or self._pp_key != key:
+            self._pp, self._pp_key = ops.pack_upsample2x_weights(self.conv.weight, self.conv.bias), key
+        return self._pp
+
+    _pp = None
+    _pp_key = None
+
+    def _apply(self, fn, *a, **k):
+        self._pp = None
+        return super()._apply(fn, *a, **k)
+
     def tokens(self, x, g: Grid, output_size=None):
         up = (2 * g.h, 2 * g.w) if output_size is None else tuple(int(s) for s in output_size)
+        c = x.shape[-1]
+        if up == (2 * g.h, 2 * g.w) and c % 64 == 0 and self.conv.out_channels % 8 == 0 and UPSAMPLE_AS_PARITY_CONVS:
+            # exact x2: four 2x2 convolutions on the stored grid, each writing one output parity class (4/9 of the multiply-adds)
+            out = torch.empty(g.images * up[0] * up[1], self.conv.out_channels, dtype=x.dtype, device=x.device)
+            for (a, b), pw in self.parity_packed().items():
+                geom = ops.Geom(g.images, g.h, g.w, g.h, g.w, 1, 1 - a, 1 - b)
+                ops.conv_gemm(x, pw, geom, out=out, out_map=(2, 2, a, b))
+            return out, g.resized(*up)
         geom = ops.conv3x3_geom(g.images, g.h, g.w, up_to=up)
         return self.conv.tokens(x, geom), g.resized(*up)
 

@@ -314,6 +314,30 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     return PackedWeight(out.contiguous(), None if b is None else b.contiguous(), n, kh, kw, cpad, gran if geglu else 0, k_order)
 
 
+def pack_upsample2x_weights(weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """Nearest x2 upsample + 3x3 / pad 1 convolution (diffusers Upsample2D) == four 2x2 convolutions on the STORED grid, one per
+    output parity class (a, b) = (Y & 1, X & 1): virtual rows Y-1, Y, Y+1 of output row Y = 2y + a read stored rows
+    (y-1, y, y) for a = 0 and (y, y, y+1) for a = 1 - the taps that read the same stored pixel are summed here (fp32, one
+    rounding).  Returns {(a, b): PackedWeight of the [N, C, 2, 2] filter}; class (a, b) runs with padding (1 - a, 1 - b) and
+    out_map (2, 2, a, b).  4/9 of the multiply-adds of the 3x3 form; zero padding of the virtual grid == zero padding of the
+    stored grid for every class (the summed taps of a class fall inside or outside together)."""
+    n, c, kh, kw = weight.shape
+    assert kh == 3 and kw == 3
+    w = weight.detach().float()
+    groups = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}          # parity -> taps of the two stored rows / columns
+    out = {}
+    for a in (0, 1):
+        for b in (0, 1):
+            f = torch.zeros(n, c, 2, 2, dtype=torch.float32, device=w.device)
+            for r, dys in enumerate(groups[a]):
+                for q, dxs in enumerate(groups[b]):
+                    for dy in dys:
+                        for dx in dxs:
+                            f[:, :, r, q] += w[:, :, dy, dx]
+            out[(a, b)] = pack_weight(f.to(weight.dtype), bias)
+    return out
+
+
 # ------------------------------------------------------------------------------------- contraction
 @dataclass
 class Geom:
@@ -361,8 +385,13 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
               rowvec: Optional[torch.Tensor] = None, rowvec_div: int = 1,
               residual: Optional[torch.Tensor] = None, act: int = AA_ACT_NONE, out_dtype=None,
               out_scale: float = 1.0, bias_per_row: bool = False, out: Optional[torch.Tensor] = None,
-              bias: Optional[torch.Tensor] = "packed", acc_scale: float = 1.0) -> torch.Tensor:
+              bias: Optional[torch.Tensor] = "packed", acc_scale: float = 1.0, out_map=None) -> torch.Tensor:
+    """`out_map` = (sy, sx, oy, ox): GEMM row (img, y, x) goes to pixel (y * sy + oy, x * sx + ox) of the [n_img, h_out * sy,
+    w_out * sx] grid that `out` (required then) holds - AaConvGemm.out_sy .. out_ox."""
     lib = _lib.get()
+    osc = 1 if out_map is None else out_map[0] * out_map[1]
+    if out_map is not None and (out is None or out.shape[0] != g.rows * osc):
+        raise RuntimeError("conv_gemm: out_map needs `out` = the whole [n_img * h_out * sy * w_out * sx, N] grid")
     b = pw.bias if isinstance(bias, str) else bias
     _check(x0, x1, pw.w, b, residual, out)
     if rowvec is not None:                                 # may be a column slice of a wider matrix (row pitch = stride(0))
@@ -374,7 +403,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     # 512x512 x 16 frames) are cut along the image axis - images are independent rows of the implicit GEMM.
     n_cols_ = pw.n_out // 2 if pw.geglu else pw.n_out
     in_rows = g.n_img * g.h_in * g.w_in
-    biggest = 2 * max(in_rows * max(c0, c1), g.rows * max(n_cols_ if out is None else out.stride(0),
+    biggest = 2 * max(in_rows * max(c0, c1), g.rows * max(osc * (n_cols_ if out is None else out.stride(0)),
                                                           0 if residual is None else residual.stride(0)))
     if biggest >= MAX_OPERAND_BYTES and g.n_img > 1 and not bias_per_row:
         if out is None:
@@ -391,7 +420,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
                 rv = rowvec[(i0 * ro) // rowvec_div:]
             conv_gemm(x0[i0 * ri:(i0 + n) * ri], pw, gi, None if x1 is None else x1[i0 * ri:(i0 + n) * ri], rv, rowvec_div,
                       None if residual is None else residual[i0 * ro:(i0 + n) * ro], act, out_dtype, out_scale, False,
-                      out[i0 * ro:(i0 + n) * ro], bias, acc_scale)
+                      out[i0 * ro * osc:(i0 + n) * ro * osc], bias, acc_scale, out_map)
         return out
     if c0 + c1 != pw.cin:
         raise RuntimeError(f"conv_gemm: activation has {c0}+{c1} channels, weight expects {pw.cin}")
@@ -415,6 +444,8 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.act, d.geglu, d.bias_per_row = act, int(pw.geglu), int(bias_per_row)
     d.dtype, d.out_dtype, d.out_scale = _DT[x0.dtype], _DT[odt], out_scale
     d.acc_scale = 0.0 if acc_scale == 1.0 else float(acc_scale)
+    if out_map is not None:
+        d.out_sy, d.out_sx, d.out_oy, d.out_ox = (int(v) for v in out_map)
     if acc_scale == 0.0:
         raise ValueError("conv_gemm: acc_scale == 0 is not representable (0 means 1 in the C ABI)")
     d.k_order = pw.k_order

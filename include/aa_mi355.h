@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AA_VERSION 104
+#define AA_VERSION 105
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
@@ -96,6 +96,26 @@ typedef struct AaConvGemm {
     int32_t rowvec_ld;     /* row pitch of `rowvec` in elements (a slice of a wider matrix); 0 = n_out */
     float acc_scale;       /* factor on the activated value in front of the residual add; 0 means 1 (version 102: the learned
                               spatial/temporal blend of diffusers AlphaBlender, x_spatial + (1 - alpha) * temporal branch) */
+    int32_t out_sy, out_sx; /* version 105.  0 / 1: GEMM row m = output row m.  > 1: GEMM row (img, y, x) of the [n_img, h_out, w_out]
+                              grid is written to pixel (y * out_sy + out_oy, x * out_sx + out_ox) of an [n_img, h_out * out_sy,
+                              w_out * out_sx] output grid (`out` points at that grid; rowvec / residual stay indexed by GEMM row).
+                              Upsample2D (nearest x2 + 3x3 convolution, unet_3d_blocks.py:709,819) is carried out as four 2x2
+                              convolutions on the STORED grid - one per output parity class, the 3x3 taps that read the same
+                              stored pixel pre-summed at pack time: 4/9 of the multiply-adds, identical result up to the
+                              rounding of the summed weights */
+    int32_t out_oy, out_ox;
+    /* version 105: LayerNorm folded into the contraction that consumes it (diffusers BasicTransformerBlock: norm1 -> to_q|to_k|to_v,
+     * norm2 -> to_q, norm3 -> GEGLU.proj; the LayerNorm kernel and the normalised tensor disappear).  With W' = W diag(gamma):
+     *   LN(x) W^T + b  =  rstd[m] * (x W'^T)[m, n]  -  rstd[m] * mean[m] * colsum(W')[n]  +  (b + beta W^T)[n]
+     * The row statistics come from the epilogue of the contraction that PRODUCED x (row_stats). */
+    const float* ln_stats;  /* consumer: [M][ln_parts][2] fp32 partial (sum, sum of squares) of each row of the A operand; NULL = no fold */
+    const float* ln_cols;   /* consumer: [2][n_pad] fp32: colsum(W')[n], then (b + beta W^T)[n]; `bias` must be NULL */
+    int32_t ln_parts;
+    float ln_eps;
+    float* row_stats;       /* producer: [M][row_stats_parts][2] fp32: (sum, sum of squares) of the stored output row over the columns of
+                               one wave of the tile - written iff row_stats_parts == aa_conv_gemm_row_stats_parts(d) > 0 */
+    int32_t row_stats_parts;
+    int32_t _pad105;
 } AaConvGemm;
 
 /* Bytes of fp32 scratch with which aa_conv_gemm would split the K loop of this call over several workgroups
@@ -105,6 +125,10 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream);
 /* Number of kernel launches aa_conv_gemm makes for this descriptor (version 103): 1, plus a launch for a split-off last
  * round of tiles, plus split-K reduce launches - what a profiler counts per call (bench.py `roofline.kernel_launches_per_step`). */
 int aa_conv_gemm_launch_count(const AaConvGemm* d);
+/* Partial row statistics per output row that aa_conv_gemm would write for this descriptor when `row_stats` is set (version 105):
+ * 0 when the way it carries the call out cannot emit them (compiled tiles, K splits, a split-off last round) - the caller then runs
+ * the LayerNorm it wanted to fold as a kernel. */
+int aa_conv_gemm_row_stats_parts(const AaConvGemm* d);
 
 /* Tile table of the LDS-DMA contraction kernel (what `AaConvGemm.tile` indexes): fills info[0..6] = rows, columns, wave
  * rows, wave columns, K step, ring stages, workgroups per CU of entry `idx`; returns 0, or -1 past the end of the table. */

@@ -368,6 +368,44 @@ def test_conv3x3_dma_path(backend, stride, pad, up_to, c1):
     close(y, ref)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,tile", [(2, 5, 7, 64, 72, -1), (3, 9, 11, 128, 320, -1), (3, 9, 11, 128, 320, 49), (2, 8, 8, 64, 256, 36),
+                                                  (2, 8, 8, 64, 256, 1), (2, 8, 8, 64, 256, 47)])
+def test_upsample2x_as_four_parity_convs(backend, n, h, w, cin, cout, tile):
+    """Upsample2D at exactly x2 (nearest + 3x3 / pad 1, unet_3d_blocks.py:709,819) carried out as four 2x2 convolutions on the
+    stored grid, each scattering into one output parity class (AaConvGemm.out_sy .. out_ox; ops.pack_upsample2x_weights):
+    == F.conv2d(F.interpolate(x, nearest x2)) and == the 3x3 gather form of the library; general, branch-free and split-K
+    epilogues (tile -1: automatic)."""
+    x, wt, b = rnd(n, cin, h, w, seed=141), rnd(cout, cin, 3, 3, scale=0.05, seed=142), rnd(cout, seed=143)
+    tok = nhwc(x)
+    out = torch.full((n * 4 * h * w, cout), float("nan"), dtype=DT, device=DEV)
+    ops.FORCE_TILE = tile
+    try:
+        for (a, bb), pw in ops.pack_upsample2x_weights(wt, b).items():
+            assert (pw.kh, pw.kw) == (2, 2)
+            ops.conv_gemm(tok, pw, ops.Geom(n, h, w, h, w, 1, 1 - a, 1 - bb), out=out, out_map=(2, 2, a, bb))
+    finally:
+        ops.FORCE_TILE = -1
+    ref = nhwc(F.conv2d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), wt.float(), b.float(), padding=1))
+    assert torch.isfinite(out.float()).all()                       # every output pixel belongs to exactly one class
+    close(out, ref)
+    gather = ops.conv_gemm(tok, ops.pack_weight(wt, b), ops.conv3x3_geom(n, h, w, up_to=(2 * h, 2 * w)))
+    close(out, gather.float(), tol=1e-2)
+
+
+def test_upsample2x_parity_convs_split_k(backend):
+    """... and through the split-K reduce launch (the 8x8 -> 16x16 upsample of the UNet runs 2176 rows x K = 5120)."""
+    n, h, w, cin, cout = 1, 4, 4, 256, 128
+    x, wt, b = rnd(n, cin, h, w, seed=151), rnd(cout, cin, 3, 3, scale=0.03, seed=152), rnd(cout, seed=153)
+    out = torch.full((n * 4 * h * w, cout), float("nan"), dtype=DT, device=DEV)
+    ops.K_SPLITS = 3
+    try:
+        for (a, bb), pw in ops.pack_upsample2x_weights(wt, b).items():
+            ops.conv_gemm(nhwc(x), pw, ops.Geom(n, h, w, h, w, 1, 1 - a, 1 - bb), out=out, out_map=(2, 2, a, bb))
+    finally:
+        ops.K_SPLITS = 0
+    close(out, nhwc(F.conv2d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), wt.float(), b.float(), padding=1)))
+
+
 def test_linear_and_tconv_dma_path(backend):
     M, K, N = 300, 128, 320                       # n_pad 320 -> 64-wide tiles
     x, w, b, r = rnd(M, K, seed=46), rnd(N, K, scale=0.1, seed=47), rnd(N, seed=48), rnd(M, N, seed=49)
