@@ -532,6 +532,19 @@ size_t aa_conv_gemm_workspace(const AaConvGemm* d) {
     return cg_plan(*d, M, true).workspace;
 }
 
+int aa_conv_gemm_row_stats_parts(const AaConvGemm* d) {
+    using namespace aa;
+    if (!d || !cg_dma_ok(*d) || d->geglu || d->rowvec || d->act != AA_ACT_NONE || d->bias_per_row || d->ln_stats || cgd_out_mapped(*d)) return 0;
+    const int M = (int)((int64_t)d->n_img * d->h_out * d->w_out);
+    CgPlan pl = cg_plan(*d, M, d->workspace != nullptr);
+    if (pl.cfg < 0) return 0;
+    if (pl.workspace > (size_t)d->workspace_bytes) pl = cg_plan(*d, M, false);
+    const CgCfg& c = kCgCfgs[pl.cfg];
+    // only the branch-free epilogue forms of the hand-scheduled tiles emit them, in ONE launch that covers every row
+    if (!c.x || pl.splits > 1 || pl.m_main < M || (d->debug & 8)) return 0;
+    return (d->n_pad / c.bn) * c.wn;
+}
+
 int aa_conv_gemm_launch_count(const AaConvGemm* d) {
     using namespace aa;
     if (!d) return 0;
@@ -565,6 +578,13 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream) {
     if (d->act != AA_ACT_NONE && d->act != AA_ACT_SILU) return fail(AA_E_SHAPE, "conv_gemm: activation %d is not fused here (AA_ACT_NONE / AA_ACT_SILU)", d->act);
     if (d->out_sy < 0 || d->out_sx < 0 || d->out_oy < 0 || d->out_ox < 0 || d->out_oy >= (d->out_sy > 1 ? d->out_sy : 1) || d->out_ox >= (d->out_sx > 1 ? d->out_sx : 1))
         return fail(AA_E_SHAPE, "conv_gemm: bad output grid mapping (out_sy=%d out_sx=%d out_oy=%d out_ox=%d)", d->out_sy, d->out_sx, d->out_oy, d->out_ox);
+    if (d->ln_stats) {
+        if (!d->ln_cols || d->ln_parts <= 0 || d->bias || d->rowvec || d->residual || d->act != AA_ACT_NONE || d->bias_per_row || d->c1 ||
+            d->kh * d->kw != 1 || d->out_scale != 1.0f || (d->acc_scale != 0.0f && d->acc_scale != 1.0f) || !cg_dma_ok(*d) || cgd_out_mapped(*d))
+            return fail(AA_E_SHAPE, "conv_gemm: the LayerNorm fold (ln_stats) is a plain or GEGLU linear call: ln_cols + ln_parts, no bias / row vector / residual / activation / scales");
+    }
+    if (d->row_stats && d->row_stats_parts != aa_conv_gemm_row_stats_parts(d))
+        return fail(AA_E_SHAPE, "conv_gemm: row_stats_parts=%d, this call emits %d partial statistics per row (aa_conv_gemm_row_stats_parts)", d->row_stats_parts, aa_conv_gemm_row_stats_parts(d));
     if (cgd_out_mapped(*d) && !cg_dma_ok(*d)) return fail(AA_E_SHAPE, "conv_gemm: a scattered output grid needs the LDS-DMA path (channels %% 64, 16-byte rows, < 2 GiB)");
     // a tile named in the descriptor is a demand, not a hint: a call it cannot carry out fails (it used to fall through to the
     // automatic choice, so a "forced tile" test could pass without running that tile).  The thread-local override of

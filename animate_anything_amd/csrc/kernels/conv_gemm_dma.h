@@ -69,7 +69,7 @@ __device__ __forceinline__ LnRow cgd_ln_row(const AaConvGemm& p, const int m) {
 template <typename T, int MI, int NI, bool GEGLU, bool RV, bool POST, bool BIAS, bool LNF, bool STATS, typename Get>
 __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW, const int part,
                                                   const float* sLn, const int ln_w) {
-    // sLn: LDS copy of colsum(W') [ln_w] and b' [ln_w] of this WAVE's columns (nullptr: read AaConvGemm.ln_cols), LNF only
+    // sLn: LDS copy of colsum(W') [ln_w] and b' [ln_w] of this WAVE's columns (LNF only)
     static_assert(!GEGLU || (NI % 2 == 0 && !RV && !POST), "GEGLU pairs value block j with gate block j + 1");
     static_assert(!LNF || (!RV && !POST && !BIAS && !STATS), "the LayerNorm fold covers the plain and the GEGLU form");
     static_assert(!STATS || !GEGLU, "row statistics: plain / residual forms");
@@ -119,7 +119,7 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
     };
     prefetch(IntTag<0>());
     // LayerNorm fold: scale / offset of this lane's row of every block row; colsum(W') and b' of the wave's columns sit in LDS
-    // (sLn: [2][columns of the wave], fp32) or, for callers without an LDS copy, are read from AaConvGemm.ln_cols
+    // (sLn: [2][columns of the wave], fp32)
     LnRow lnr[LNF ? MI : 1];
     if constexpr (LNF) {
 #pragma unroll
@@ -166,15 +166,18 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
                 }
             }
             auto ln_apply = [&](float (&x)[16], const int jj) __attribute__((always_inline)) {       // x = a * x + nm * colsum + b'
+              if constexpr (LNF) {
                 const int cw = jj * 32 + 16 * eh;                       // first of this lane's 16 columns, counted from n_wave
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     f32x4 cs, bb;
-                    if (sLn) { cs = *reinterpret_cast<const f32x4*>(sLn + cw + 4 * q4); bb = *reinterpret_cast<const f32x4*>(sLn + ln_w + cw + 4 * q4); }
-                    else { cs = *reinterpret_cast<const f32x4*>(p.ln_cols + n_wave + cw + 4 * q4); bb = *reinterpret_cast<const f32x4*>(p.ln_cols + p.n_pad + n_wave + cw + 4 * q4); }
+                    // (LDS only: a select between an LDS and a global pointer here crashes hipcc 7.2's SimplifyCFG)
+                    cs = *reinterpret_cast<const f32x4*>(sLn + cw + 4 * q4);
+                    bb = *reinterpret_cast<const f32x4*>(sLn + ln_w + cw + 4 * q4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[4 * q4 + e] = fmaf(x[4 * q4 + e], lnr[i].a, fmaf(lnr[i].nm, cs[e], bb[e]));
                 }
+              }
             };
             if constexpr (LNF) ln_apply(v, j);
             if constexpr (GEGLU) {

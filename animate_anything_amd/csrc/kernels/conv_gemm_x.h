@@ -24,7 +24,8 @@
 
 namespace aa {
 
-__host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring) { return cgd_lds_bytes(bm, bn, bk, ring); }
+// (+ the LayerNorm fold's column vectors of the tile: colsum(W') and b', fp32)
+__host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring) { return cgd_lds_bytes(bm, bn, bk, ring) + bn * 8; }
 
 // DP3 / DP0 / DP1: LDS-DMA pieces (per wave) of the tile after next issued under sub-step 3 of a K step and under
 // sub-steps 0 / 1 of the following one (the rest under sub-step 2); activations first (they may come from HBM).
@@ -74,6 +75,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     char* smem = dyn_smem();
     char* dummy = smem + STAGES * STAGE_BYTES;
     T* sBias = reinterpret_cast<T*>(dummy + 1024);
+    float* sLn = reinterpret_cast<float*>(dummy + 2048);    // [2][BN]: AaConvGemm.ln_cols of this tile's columns (LayerNorm fold)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -327,6 +329,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
 
     auto put_bias = [&]() __attribute__((always_inline)) {       // the general epilogue path adds a bias slice from LDS: zeros here, the
         if (tid < BN / 8) *reinterpret_cast<u32x4*>(sBias + tid * 8) = u32x4{0u, 0u, 0u, 0u};     // accumulators already carry the bias
+        if (p.ln_cols) {                                         // (published by the K loop's barriers, like the bias slice)
+            for (int c = tid; c < 2 * BN; c += 64 * NW) {
+                const int half = c >= BN ? 1 : 0, col = tile_n * BN + c - half * BN;
+                sLn[c] = col < p.n_pad ? p.ln_cols[(int64_t)half * p.n_pad + col] : 0.0f;
+            }
+        }
         start_from_bias();
     };
     if constexpr (BK == 64) {
@@ -429,7 +437,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         return;
     }
     cgd_epilogue_g<T, MI, NI, true>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) { return acc_get<decltype(i_)::value * NI + decltype(j_)::value>(af); },
-                              m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN));
+                              m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN),
+                              p.row_stats ? tile_n * WN + wn : -1, p.ln_cols ? sLn + wn * (BN / WN) : nullptr, BN);
     stamp(5);
     stamp_wall(4, -1);
 }

@@ -70,6 +70,8 @@ class _Packed:
         return self._pw
 
 
+LN_FOLD = True       # BasicTransformerBlock: LayerNorm folded into the contraction that consumes it (ops.pack_weight(ln=...)), the row
+                     # statistics taken from the epilogue of the contraction that produced the tensor; False = LayerNorm kernels
 UPSAMPLE_AS_PARITY_CONVS = True      # Upsample2D at exactly x2: four 2x2 convolutions (ops.pack_upsample2x_weights); False = the 3x3 gather form
 
 
@@ -270,6 +272,7 @@ class Attention(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._fused = None
+        self._fused_ln = None
         return super()._apply(fn, *a, **k)
 
     def fused(self):
@@ -279,6 +282,18 @@ class Attention(nn.Module):
         if self._fused is None or self._fused_key != key:
             self._fused, self._fused_key = ops.pack_weight(torch.cat([r.detach() for r in rows], dim=0)), key
         return self._fused
+
+    def fused_ln(self, norm):
+        """The Q|K|V rows (self-attention) or the Q rows (cross-attention) with `norm` - the LayerNorm in front - folded in."""
+        rows = [self.to_q.weight] if self.is_cross else [self.to_q.weight, self.to_k.weight, self.to_v.weight]
+        key = weights_key(*rows, norm.weight, norm.bias)
+        if self._fused_ln is None or self._fused_ln_key != key:
+            self._fused_ln = ops.pack_weight(torch.cat([r.detach() for r in rows], dim=0), None, ln=(norm.weight, norm.bias, norm.eps))
+            self._fused_ln_key = key
+        return self._fused_ln
+
+    _fused_ln = None
+    _fused_ln_key = None
 
     def text_kv(self, text_tokens):
         """[clips*L, cross_dim] -> [clips*L, 2*inner] (K | V): normally a column slice of ONE projection of the text for
@@ -294,8 +309,13 @@ class Attention(nn.Module):
         kv = self.text_kv(text_tokens)
         return self.to_out[0].tokens(kv[:, self.inner:].contiguous())
 
-    def self_tokens(self, normed, residual, g: Grid, temporal: bool, **epilogue):
-        qkv = ops.conv_gemm(normed, self.fused(), ops.linear_geom(normed.shape[0]))
+    def self_tokens(self, normed, residual, g: Grid, temporal: bool, ln=None, **epilogue):
+        """`ln` = (LayerNorm module, ops.RowStats of `normed`'s rows): `normed` is then the UN-normalised tensor and the
+        LayerNorm is folded into the Q|K|V projection.  `row_stats=True` (epilogue) returns (out, RowStats or None)."""
+        if ln is None:
+            qkv = ops.conv_gemm(normed, self.fused(), ops.linear_geom(normed.shape[0]))
+        else:
+            qkv = ops.conv_gemm(normed, self.fused_ln(ln[0]), ops.linear_geom(normed.shape[0]), ln_stats=ln[1])
         c = self.inner
         if temporal:
             st = (g.frames * g.hw, 1, g.hw)
@@ -305,11 +325,14 @@ class Attention(nn.Module):
             a = ops.attention(qkv, 0, qkv, c, qkv, 2 * c, self.heads, g.images, 1, g.hw, g.hw, st, st)
         return self.to_out[0].tokens(a, residual=residual, **epilogue)
 
-    def cross_tokens(self, normed, residual, g: Grid, kv, kv_len):
-        q = self.to_q.tokens(normed)
+    def cross_tokens(self, normed, residual, g: Grid, kv, kv_len, ln=None, **epilogue):
+        if ln is None:
+            q = self.to_q.tokens(normed)
+        else:                                             # (see self_tokens)
+            q = ops.conv_gemm(normed, self.fused_ln(ln[0]), ops.linear_geom(normed.shape[0]), ln_stats=ln[1])
         a = ops.attention(q, 0, kv, 0, kv, self.inner, self.heads, g.images, 1, g.hw, kv_len,
                           (g.hw, 0, 1), (kv_len, 0, 1), kv_outer_div=g.frames)
-        return self.to_out[0].tokens(a, residual=residual)
+        return self.to_out[0].tokens(a, residual=residual, **epilogue)
 
     def cross_tokens_temporal(self, normed, residual, g: Grid, kv, kv_len, kv_seq_mod=0):
         """Queries = the frames of one pixel, keys = a clip's context tokens (diffusers TemporalBasicTransformerBlock.attn2);
@@ -329,6 +352,7 @@ class GEGLU(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._pw = None
+        self._pw_ln = None
         return super()._apply(fn, *a, **k)
 
     def packed(self):
@@ -337,8 +361,20 @@ class GEGLU(nn.Module):
             self._pw, self._pw_key = ops.pack_weight(self.proj.weight, self.proj.bias, geglu=True), key
         return self._pw
 
-    def tokens(self, x):
-        return ops.conv_gemm(x, self.packed(), ops.linear_geom(x.shape[0]))
+    def packed_ln(self, norm):
+        key = weights_key(self.proj.weight, self.proj.bias, norm.weight, norm.bias)
+        if self._pw_ln is None or self._pw_ln_key != key:
+            self._pw_ln = ops.pack_weight(self.proj.weight, self.proj.bias, geglu=True, ln=(norm.weight, norm.bias, norm.eps))
+            self._pw_ln_key = key
+        return self._pw_ln
+
+    _pw_ln = None
+    _pw_ln_key = None
+
+    def tokens(self, x, ln=None):
+        if ln is None:
+            return ops.conv_gemm(x, self.packed(), ops.linear_geom(x.shape[0]))
+        return ops.conv_gemm(x, self.packed_ln(ln[0]), ops.linear_geom(x.shape[0]), ln_stats=ln[1])
 
 
 class FeedForward(nn.Module):
@@ -346,8 +382,8 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim_out or dim)])
 
-    def tokens(self, x, residual):
-        return self.net[2].tokens(self.net[0].tokens(x), residual=residual)
+    def tokens(self, x, residual, ln=None):
+        return self.net[2].tokens(self.net[0].tokens(x, ln=ln), residual=residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -361,19 +397,34 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.double_self_attention = double_self_attention
 
-    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0, dup: int = 1):
+    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0, dup: int = 1, x_stats=None):
         """`dup` > 1: x holds ONE copy of `dup` identical groups of clips (classifier-free guidance runs the same latents
         with two prompts, models/pipeline.py:165): the self-attention - which never sees the text - is computed once and
-        its result replicated in front of the cross-attention; `g` describes the single copy."""
-        x = self.attn1.self_tokens(self.norm1.tokens(x), x, g, temporal)
+        its result replicated in front of the cross-attention; `g` describes the single copy.
+        `x_stats`: ops.RowStats of x left by the contraction that produced it.  With LN_FOLD the three LayerNorms never run as
+        kernels: each is folded into the projection behind it (Q|K|V, Q, GEGLU) and its row statistics come out of the epilogue
+        of the projection in front of it (proj_in, to_out + residual); a producer that cannot emit them (split K, compiled
+        tiles) leaves None and that LayerNorm runs as a kernel."""
+        fold = LN_FOLD
+        if fold and x_stats is not None:
+            x, st = self.attn1.self_tokens(x, x, g, temporal, ln=(self.norm1, x_stats), row_stats=True)
+        else:
+            x, st = self.attn1.self_tokens(self.norm1.tokens(x), x, g, temporal, row_stats=True) if fold else \
+                    (self.attn1.self_tokens(self.norm1.tokens(x), x, g, temporal), None)
         if dup > 1:
             x = torch.cat([x] * dup)
+            st = None if st is None else st.repeat(dup)
             g = replace(g, clips=g.clips * dup)
+        ln2 = None if st is None else (self.norm2, st)
+        xin = x if ln2 is not None else self.norm2.tokens(x)
         if self.attn2.is_cross:
             kv = self.attn2.text_kv(text)
-            x = self.attn2.cross_tokens(self.norm2.tokens(x), x, g, kv, text_len)
+            r = self.attn2.cross_tokens(xin, x, g, kv, text_len, ln=ln2, row_stats=fold)
         else:
-            x = self.attn2.self_tokens(self.norm2.tokens(x), x, g, temporal)
+            r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, row_stats=fold)
+        x, st = r if fold else (r, None)
+        if st is not None:
+            return self.ff.tokens(x, residual=x, ln=(self.norm3, st))
         return self.ff.tokens(self.norm3.tokens(x), residual=x)
 
 
@@ -390,9 +441,10 @@ class Transformer2DModel(nn.Module):
 
     def tokens(self, x, g: Grid, text, text_len, dup: int = 1):
         """`dup` > 1 (see BasicTransformerBlock.tokens): x / g are the single copy, the result covers all `dup` groups."""
-        h = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw))
+        h, st = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw), row_stats=True) if LN_FOLD else \
+                (self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw)), None)
         for i, blk in enumerate(self.transformer_blocks):
-            h = blk.tokens(h, g, temporal=False, text=text, text_len=text_len, dup=dup if i == 0 else 1)
+            h = blk.tokens(h, g, temporal=False, text=text, text_len=text_len, dup=dup if i == 0 else 1, x_stats=st if i == 0 else None)
             if i == 0 and dup > 1:
                 g = replace(g, clips=g.clips * dup)
         return self.proj_out.tokens(h, residual=torch.cat([x] * dup) if dup > 1 else x)
@@ -412,7 +464,8 @@ class TransformerTemporalModel(nn.Module):
         self.proj_out = Linear(inner, in_channels)
 
     def tokens(self, x, g: Grid):
-        h = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw))
-        for blk in self.transformer_blocks:
-            h = blk.tokens(h, g, temporal=True)
+        h, st = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw), row_stats=True) if LN_FOLD else \
+                (self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw)), None)
+        for i, blk in enumerate(self.transformer_blocks):
+            h = blk.tokens(h, g, temporal=True, x_stats=st if i == 0 else None)
         return self.proj_out.tokens(h, residual=x)

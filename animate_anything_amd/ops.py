@@ -153,6 +153,16 @@ def _autotune(lib, d, stream, key, rows, dev):
     global AUTOTUNE_EVENTS
     AUTOTUNE_EVENTS += 1
     cands = _tile_candidates(d, rows)
+    if "stats" in key:                                   # the caller wants the row statistics: only ways of carrying the call out that emit them
+        def emits(c, sp):
+            d.tile, d.k_splits = c, sp
+            need = lib.aa_conv_gemm_workspace(C.byref(d))
+            keep = (d.workspace, d.workspace_bytes)
+            d.workspace, d.workspace_bytes = (C.c_void_p(1), need) if need else (None, 0)      # (only its presence is looked at)
+            n = lib.aa_conv_gemm_row_stats_parts(C.byref(d))
+            d.workspace, d.workspace_bytes = keep
+            return n > 0
+        cands = [c for c in cands if emits(*c)] or cands
     best = (-1, 0)
     if len(cands) > 1:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -258,6 +268,8 @@ class PackedWeight:
     cin: int          # channels per tap as stored (after padding to a multiple of 8)
     geglu: int = 0    # 0, or the value/gate interleave granularity of a GEGLU projection
     k_order: int = 0  # 0: K = (tap, channel); 1: K = (64-channel chunk, tap, channel)
+    ln_cols: Optional[torch.Tensor] = None   # LayerNorm folded into these weights: fp32 [2, n_pad] = colsum(W'), b + beta W^T
+    ln_eps: float = 0.0
 
     @property
     def n_pad(self):
@@ -268,13 +280,25 @@ class PackedWeight:
         return self.w.shape[1]
 
 
-def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu: bool = False) -> PackedWeight:
+def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu: bool = False, ln=None) -> PackedWeight:
     """Pack an nn.Linear [n,k], nn.Conv2d [n,c,kh,kw] or nn.Conv3d [n,c,kt,1,1] weight.
 
     GEGLU (diffusers `GEGLU.proj`, rows [0,d) = value, [d,2d) = gate) is re-ordered into alternating
     blocks of 32 value rows / 32 gate rows: a value block and its gate block are then neighbouring accumulator
-    blocks of the same wavefront and the gating happens in registers."""
+    blocks of the same wavefront and the gating happens in registers.
+
+    `ln` = (gamma, beta, eps) folds the LayerNorm in front of an nn.Linear into it (AaConvGemm.ln_stats):
+    LN(x) W^T + b = rstd (x W'^T) - rstd mean colsum(W') + (b + beta W^T) with W' = W diag(gamma) rounded to the storage type;
+    colsum is taken over the ROUNDED W', so the mean term cancels exactly what the matrix cores accumulate."""
     w = weight.detach()
+    b_ln = None
+    if ln is not None:
+        gamma, beta, eps = ln
+        assert w.dim() == 2, "the LayerNorm fold is for nn.Linear weights"
+        wf = w.float()
+        b_ln = wf @ beta.detach().float() + (0.0 if bias is None else bias.detach().float())      # fp32 [n]
+        w = (wf * gamma.detach().float()[None, :]).to(w.dtype)
+        bias = None
     if w.dim() == 2:
         n, kh, kw, cin = w.shape[0], 1, 1, w.shape[1]
         w4 = w.reshape(n, 1, 1, cin)
@@ -306,12 +330,20 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
         src = torch.cat([val, val + d], dim=1).reshape(-1)
         w2 = w2[src]
         b = None if b is None else b[src]
+        b_ln = None if b_ln is None else b_ln[src]
     n_pad, k_pad = _round_up(n, 64), _round_up(k, 64)
     out = torch.zeros(n_pad, k_pad, dtype=w.dtype, device=w.device)
     out[:n, :k] = w2
     if b is not None and geglu and n_pad != n:
         b = torch.nn.functional.pad(b, (0, n_pad - n))
-    return PackedWeight(out.contiguous(), None if b is None else b.contiguous(), n, kh, kw, cpad, gran if geglu else 0, k_order)
+    ln_cols, ln_eps = None, 0.0
+    if ln is not None:
+        ln_cols = torch.zeros(2, n_pad, dtype=torch.float32, device=w.device)
+        ln_cols[0] = out.float().sum(dim=1)
+        ln_cols[1, :n] = b_ln
+        ln_eps = float(ln[2])
+    return PackedWeight(out.contiguous(), None if b is None else b.contiguous(), n, kh, kw, cpad, gran if geglu else 0, k_order,
+                        ln_cols, ln_eps)
 
 
 def pack_upsample2x_weights(weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
@@ -336,6 +368,18 @@ def pack_upsample2x_weights(weight: torch.Tensor, bias: Optional[torch.Tensor] =
                             f[:, :, r, q] += w[:, :, dy, dx]
             out[(a, b)] = pack_weight(f.to(weight.dtype), bias)
     return out
+
+
+@dataclass
+class RowStats:
+    """Partial (sum, sum of squares) per row of a token matrix, [rows, parts, 2] fp32, left by the contraction that wrote it
+    (AaConvGemm.row_stats) for the contraction that folds the LayerNorm of that matrix (AaConvGemm.ln_stats)."""
+    data: torch.Tensor
+    rows: int
+    parts: int
+
+    def repeat(self, n):
+        return RowStats(torch.cat([self.data] * n), self.rows * n, self.parts)
 
 
 # ------------------------------------------------------------------------------------- contraction
@@ -385,9 +429,11 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
               rowvec: Optional[torch.Tensor] = None, rowvec_div: int = 1,
               residual: Optional[torch.Tensor] = None, act: int = AA_ACT_NONE, out_dtype=None,
               out_scale: float = 1.0, bias_per_row: bool = False, out: Optional[torch.Tensor] = None,
-              bias: Optional[torch.Tensor] = "packed", acc_scale: float = 1.0, out_map=None) -> torch.Tensor:
+              bias: Optional[torch.Tensor] = "packed", acc_scale: float = 1.0, out_map=None, ln_stats=None, row_stats: bool = False):
     """`out_map` = (sy, sx, oy, ox): GEMM row (img, y, x) goes to pixel (y * sy + oy, x * sx + ox) of the [n_img, h_out * sy,
-    w_out * sx] grid that `out` (required then) holds - AaConvGemm.out_sy .. out_ox."""
+    w_out * sx] grid that `out` (required then) holds - AaConvGemm.out_sy .. out_ox.
+    `ln_stats` = RowStats of x0's rows (from the call that produced x0): `pw` must carry a folded LayerNorm (pack_weight(ln=...)).
+    `row_stats=True`: returns (out, RowStats or None) - the partial row statistics of `out` when this call can emit them."""
     lib = _lib.get()
     osc = 1 if out_map is None else out_map[0] * out_map[1]
     if out_map is not None and (out is None or out.shape[0] != g.rows * osc):
@@ -446,6 +492,12 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.acc_scale = 0.0 if acc_scale == 1.0 else float(acc_scale)
     if out_map is not None:
         d.out_sy, d.out_sx, d.out_oy, d.out_ox = (int(v) for v in out_map)
+    if ln_stats is not None:
+        if pw.ln_cols is None or ln_stats.rows != g.rows:
+            raise RuntimeError("conv_gemm: ln_stats needs weights packed with a folded LayerNorm and statistics of every row of x0")
+        d.ln_stats, d.ln_cols, d.ln_parts, d.ln_eps = _ptr(ln_stats.data), _ptr(pw.ln_cols), ln_stats.parts, pw.ln_eps
+    elif pw.ln_cols is not None:
+        raise RuntimeError("conv_gemm: these weights carry a folded LayerNorm: pass the row statistics of x0 (ln_stats)")
     if acc_scale == 0.0:
         raise ValueError("conv_gemm: acc_scale == 0 is not representable (0 means 1 in the C ABI)")
     d.k_order = pw.k_order
@@ -453,7 +505,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.tile, d.k_splits = -1, K_SPLITS
     if AUTOTUNE and x0.is_cuda:
         key = (d.dtype, g.n_img, g.h_in, g.w_in, d.h_virt, d.w_virt, g.h_out, g.w_out, g.stride, pw.kh, pw.kw, c0, c1,
-               pw.n_out, d.geglu, residual is not None)
+               pw.n_out, d.geglu, residual is not None) + (("ln",) if ln_stats is not None else ()) + (("stats",) if row_stats else ())
         _load_default_tile_cache()
         choice = _tile_cache.get(key)
         # the tuning launches write `out` repeatedly: only safe when no input of the call aliases it
@@ -473,10 +525,16 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     elif need:
         ws = torch.empty(need // 4, dtype=torch.float32, device=x0.device)
         d.workspace, d.workspace_bytes = _ptr(ws), need
+    stats = None
+    if row_stats:                                         # after tile / workspace are settled: the plan decides whether it can emit them
+        parts = lib.aa_conv_gemm_row_stats_parts(C.byref(d))
+        if parts > 0:
+            stats = RowStats(torch.empty(g.rows, parts, 2, dtype=torch.float32, device=x0.device), g.rows, parts)
+            d.row_stats, d.row_stats_parts = _ptr(stats.data), parts
     _run(lib.aa_conv_gemm, C.byref(d), _stream(x0))
     if TRACE is not None:
-        TRACE.append((d, (x0, x1, pw, b, rowvec, residual, out, ws)))
-    return out
+        TRACE.append((d, (x0, x1, pw, b, rowvec, residual, out, ws, stats, ln_stats)))
+    return (out, stats) if row_stats else out
 
 
 # ------------------------------------------------------------------------------------- norms

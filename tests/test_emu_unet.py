@@ -90,3 +90,50 @@ def test_cfg_shared_prefix_matches_full_batch(emu):
                                      [int(t) for t in pipe.scheduler.timesteps], 9.0))
     assert torch.isfinite(outs[0]).all()
     assert rel_err(outs[0], outs[1]) < 2e-3
+
+
+def test_layernorm_fold_replaces_the_layernorm_kernels(emu, monkeypatch):
+    """layers.LN_FOLD: with a tile that emits row statistics forced onto every contraction it fits (the 128 x 128 hand-scheduled
+    tile), the transformer blocks of the UNet run WITHOUT LayerNorm launches where the producer emitted statistics, and the
+    result equals the LayerNorm-kernel form of the same network (and the oracle)."""
+    from animate_anything_amd import layers, ops
+    torch.manual_seed(0)
+    ref = oracle.UNet3DConditionModel(**TINY_UNET).eval()
+    state = seeded_state(ref)
+    ref.load_state_dict(state)
+    net = UNet3DConditionModel(**TINY_UNET).eval()
+    net.load_state_dict(state)
+    net = net.half()
+    i = unet_inputs(h=6, w=6, text_len=9)
+    calls = {"ln": 0, "folded": 0}
+    real_ln, real_cg = ops.layernorm, ops.conv_gemm
+
+    def counting_ln(*a, **k):
+        calls["ln"] += 1
+        return real_ln(*a, **k)
+
+    def counting_cg(*a, **k):
+        calls["folded"] += k.get("ln_stats") is not None
+        return real_cg(*a, **k)
+    monkeypatch.setattr(ops, "layernorm", counting_ln)
+    monkeypatch.setattr(ops, "conv_gemm", counting_cg)
+
+    def run():
+        calls["ln"] = calls["folded"] = 0
+        with torch.no_grad():
+            return net(i["sample"].half(), i["t"], i["text"].half(), i["cond"].half(), i["mask"].half(), motion=i["motion"]).sample
+    lib = __import__("animate_anything_amd._lib", fromlist=["get"]).get()
+    lib.aa_set_tile_override(47)                       # preference: taken wherever the packed width is a multiple of 128
+    try:
+        monkeypatch.setattr(layers, "LN_FOLD", True)
+        folded = run()
+        n_ln_fold, n_folded = calls["ln"], calls["folded"]
+        monkeypatch.setattr(layers, "LN_FOLD", False)
+        plain = run()
+        n_ln_plain = calls["ln"]
+    finally:
+        lib.aa_set_tile_override(-1)
+    assert n_folded > 0 and n_ln_fold + n_folded == n_ln_plain and calls["folded"] == 0
+    with torch.no_grad():
+        want = ref(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
+    assert rel_err(folded, want) < 3e-2 and rel_err(plain, want) < 3e-2 and rel_err(folded, plain) < 2e-2

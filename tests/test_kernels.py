@@ -406,6 +406,65 @@ def test_upsample2x_parity_convs_split_k(backend):
     close(out, nhwc(F.conv2d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), wt.float(), b.float(), padding=1)))
 
 
+@pytest.mark.parametrize("M,C,ptile,ctile,geglu", [(300, 320, 49, 39, False), (300, 320, 39, 36, True), (520, 256, 36, 40, True), (300, 256, 38, 1, False),
+                                                 (200, 640, 49, 49, False), (300, 128, 47, 47, False), (300, 256, 46, 3, True)])
+def test_layernorm_folded_into_the_consuming_contraction(backend, M, C, ptile, ctile, geglu):
+    """diffusers BasicTransformerBlock, norm -> projection (oracle/layers.py:219-224) without a LayerNorm kernel: the producing
+    contraction (to_out + residual, hand-scheduled tile `ptile`) leaves partial (sum, sum of squares) per row of what it stores
+    (AaConvGemm.row_stats, computed on the matrix cores from the stored 16-bit values); the consuming one (Q|K|V / GEGLU, tile
+    `ctile`: branch-free forms of the hand-scheduled tiles, or the general epilogue of a compiled tile) runs on the UN-normalised
+    rows with W diag(gamma) and corrects rstd / mean / beta in its epilogue (AaConvGemm.ln_stats)."""
+    a, w0, b0, r = rnd(M, 128, seed=201), rnd(C, 128, scale=0.2, seed=202), rnd(C, seed=203), rnd(M, C, seed=204) + 3.0    # rows with mean ~3, std ~2.5
+    N = 640 if ops.TILE_TABLE[ctile][1] == 320 else 384
+    w1, b1 = rnd(2 * N if geglu else N, C, scale=0.08, seed=205), rnd(2 * N if geglu else N, seed=206)
+    gamma, beta = rnd(C, seed=207) * 0.3 + 1.0, rnd(C, seed=208) * 0.2
+    ops.FORCE_TILE = ptile
+    try:
+        y, st = ops.conv_gemm(a, ops.pack_weight(w0, b0), ops.linear_geom(M), residual=r, row_stats=True)
+    finally:
+        ops.FORCE_TILE = -1
+    assert st is not None and st.rows == M and st.data.shape == (M, st.parts, 2)
+    yf = y.float()
+    tot = st.data.float().sum(dim=1).cpu()
+    close(tot[:, 0], yf.sum(dim=1), tol=2e-3)
+    close(tot[:, 1], (yf * yf).sum(dim=1), tol=2e-3)
+    pw = ops.pack_weight(w1, b1, geglu=geglu, ln=(gamma, beta, 1e-5))
+    assert pw.bias is None and pw.ln_cols.shape == (2, pw.n_pad)
+    ops.FORCE_TILE = ctile
+    try:
+        z = ops.conv_gemm(y, pw, ops.linear_geom(M), ln_stats=st)
+    finally:
+        ops.FORCE_TILE = -1
+    h = F.layer_norm(yf, (C,), gamma.float(), beta.float(), 1e-5) @ w1.float().t() + b1.float()
+    close(z, h[:, :N] * F.gelu(h[:, N:]) if geglu else h)
+    with pytest.raises(RuntimeError):
+        ops.conv_gemm(y, pw, ops.linear_geom(M))                      # folded weights without statistics
+
+
+def test_layernorm_fold_through_split_k_and_producers_that_cannot_emit(backend):
+    """A K-split consumer applies the fold in the reduce launch; a producer that is split along K (or runs a compiled tile)
+    reports no statistics (aa_conv_gemm_row_stats_parts == 0) and the caller keeps its LayerNorm kernel."""
+    M, C, N = 200, 512, 256
+    y = rnd(M, C, seed=211) + 1.5
+    w1, b1, gamma, beta = rnd(N, C, scale=0.06, seed=212), rnd(N, seed=213), rnd(C, seed=214) * 0.3 + 1.0, rnd(C, seed=215) * 0.2
+    yf = y.float()
+    st = ops.RowStats(torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=1).reshape(M, 1, 2).contiguous().to(DEV), M, 1)
+    ops.K_SPLITS, ops.FORCE_TILE = 3, 36
+    try:
+        z = ops.conv_gemm(y, ops.pack_weight(w1, b1, ln=(gamma, beta, 1e-5)), ops.linear_geom(M), ln_stats=st)
+        _, none1 = ops.conv_gemm(y, ops.pack_weight(w1, b1), ops.linear_geom(M), row_stats=True)
+    finally:
+        ops.K_SPLITS, ops.FORCE_TILE = 0, -1
+    close(z, F.layer_norm(yf, (C,), gamma.float(), beta.float(), 1e-5) @ w1.float().t() + b1.float())
+    assert none1 is None
+    ops.FORCE_TILE = 1
+    try:
+        _, none2 = ops.conv_gemm(y, ops.pack_weight(w1, b1), ops.linear_geom(M), row_stats=True)
+    finally:
+        ops.FORCE_TILE = -1
+    assert none2 is None
+
+
 def test_linear_and_tconv_dma_path(backend):
     M, K, N = 300, 128, 320                       # n_pad 320 -> 64-wide tiles
     x, w, b, r = rnd(M, K, seed=46), rnd(N, K, scale=0.1, seed=47), rnd(N, seed=48), rnd(M, N, seed=49)
