@@ -109,7 +109,7 @@ class AaEulerStepTok(C.Structure):
     ]
 
 
-SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_conv_gemm_row_stats_parts", "aa_groupnorm_workspace", "aa_groupnorm", "aa_set_groupnorm_two_pass", "aa_groupnorm_plan",
+SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_conv_gemm_row_stats_parts", "aa_ln_finalize", "aa_groupnorm_workspace", "aa_groupnorm", "aa_set_groupnorm_two_pass", "aa_groupnorm_plan",
            "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step",
            "aa_timestep_embedding", "aa_pack_latents", "aa_cfg_dpm_step_tokens",
            "aa_blend", "aa_pack_frames", "aa_cfg_euler_step_tokens")
@@ -135,6 +135,8 @@ def bind(path: str) -> C.CDLL:
     lib.aa_conv_gemm_tile_ok.argtypes = [C.POINTER(AaConvGemm), C.c_int]
     lib.aa_conv_gemm_tile_ok.restype = C.c_int
     lib.aa_conv_gemm.argtypes = [C.POINTER(AaConvGemm), C.c_void_p]
+    lib.aa_ln_finalize.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]
+    lib.aa_ln_finalize.restype = C.c_int
     lib.aa_conv_gemm_row_stats_parts.argtypes = [C.POINTER(AaConvGemm)]
     lib.aa_conv_gemm_row_stats_parts.restype = C.c_int
     lib.aa_conv_gemm_launch_count.argtypes = [C.POINTER(AaConvGemm)]

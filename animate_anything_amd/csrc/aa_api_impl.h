@@ -147,6 +147,7 @@ static int cg_choose(const AaConvGemm& d, int M) {
         if (d.geglu && (c.bn / c.wn) % 64) continue;          // value / gate blocks pair up inside one wavefront
         if (c.slab && !cg_slab_ok(d, c)) continue;
         if (c.x && (!cg_x_ok(d) || (i >= 36 && ((g_x_disabled >> (i - 36)) & 1u)))) continue;
+        if (c.x && d.ln_stats && (c.wm * c.wn * c.per_cu > 4 || c.bk != 64)) continue;
         if (forced == i) return i;
         const double tiles = (double)((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
         const double slots = 256.0 * c.per_cu;
@@ -181,7 +182,7 @@ static bool cg_dma_ok(const AaConvGemm& d) {
            (int64_t)d.n_img * d.h_in * d.w_in * (d.c0 > d.c1 ? d.c0 : d.c1) * 2 < ((int64_t)1 << 31) &&
            (int64_t)d.n_pad * d.k_pad * 2 < ((int64_t)1 << 31) &&
            // a scattered output grid (out_sy / out_sx) is addressed through one descriptor over the whole grid
-           (!cgd_out_mapped(d) || (int64_t)d.n_img * d.h_out * d.w_out * (d.out_sy > 1 ? d.out_sy : 1) * (d.out_sx > 1 ? d.out_sx : 1) * d.ldo * 2 < ((int64_t)1 << 31));
+           (!cgd_out_mapped(d) || (int64_t)d.n_img * d.h_out * d.w_out * (d.out_sy > 1 ? d.out_sy : 1) * (d.out_sx > 1 ? d.out_sx : 1) * d.ldo * 2 < ((int64_t)1 << 31) - 32);
 }
 
 // How one aa_conv_gemm call is carried out on the LDS-DMA path (shared by aa_conv_gemm_workspace and the launcher).
@@ -262,9 +263,9 @@ static void cg_launch_x(const AaConvGemm& d, int m_begin, int m_end, int splits,
     const int tiles_n = d.n_pad / BN;
     const dim3 grid(((m_end - m_begin + BM - 1) / BM) * tiles_n, splits), block(64 * WM * WN);
     if (d.kh * d.kw == 1 && d.stride == 1 && d.pad_h == 0 && d.pad_w == 0)
-        AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1, RING, PER_CU, true>), grid, block, cgx_lds_bytes(BM, BN, BK, RING), stream, d, m_end, tiles_n, m_begin, splits);
+        AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1, RING, PER_CU, true>), grid, block, cgx_lds_bytes(BM, BN, BK, RING, WM, WN, PER_CU), stream, d, m_end, tiles_n, m_begin, splits);
     else
-        AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1, RING, PER_CU, false>), grid, block, cgx_lds_bytes(BM, BN, BK, RING), stream, d, m_end, tiles_n, m_begin, splits);
+        AA_LAUNCH((conv_gemm_x_kernel<T, BM, BN, WM, WN, BK, DP3, DP0, DP1, RING, PER_CU, false>), grid, block, cgx_lds_bytes(BM, BN, BK, RING, WM, WN, PER_CU), stream, d, m_end, tiles_n, m_begin, splits);
 }
 
 // The contraction kernels are compiled in AA_TU_GROUPS translation units (build.py compiles them in parallel: one unit took 5+
@@ -517,6 +518,7 @@ int aa_conv_gemm_tile_ok(const AaConvGemm* d, int idx) {
     if (d->geglu && (c.bn / c.wn) % 64) return 0;
     if (c.slab && !cg_slab_ok(*d, c)) return 0;
     if (c.x && (!cg_x_ok(*d) || (idx >= 36 && ((g_x_disabled >> (idx - 36)) & 1u)))) return 0;
+    if (c.x && d->ln_stats && (c.wm * c.wn * c.per_cu > 4 || c.bk != 64)) return 0;      // the LayerNorm fold starts the accumulators in one-wave-per-SIMD tiles only
     return 1;
 }
 void aa_set_tile_override(int cfg) {
@@ -579,9 +581,9 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream) {
     if (d->out_sy < 0 || d->out_sx < 0 || d->out_oy < 0 || d->out_ox < 0 || d->out_oy >= (d->out_sy > 1 ? d->out_sy : 1) || d->out_ox >= (d->out_sx > 1 ? d->out_sx : 1))
         return fail(AA_E_SHAPE, "conv_gemm: bad output grid mapping (out_sy=%d out_sx=%d out_oy=%d out_ox=%d)", d->out_sy, d->out_sx, d->out_oy, d->out_ox);
     if (d->ln_stats) {
-        if (!d->ln_cols || d->ln_parts <= 0 || d->bias || d->rowvec || d->residual || d->act != AA_ACT_NONE || d->bias_per_row || d->c1 ||
+        if (!d->ln_cols || d->bias || d->rowvec || d->residual || d->act != AA_ACT_NONE || d->bias_per_row || d->c1 ||
             d->kh * d->kw != 1 || d->out_scale != 1.0f || (d->acc_scale != 0.0f && d->acc_scale != 1.0f) || !cg_dma_ok(*d) || cgd_out_mapped(*d))
-            return fail(AA_E_SHAPE, "conv_gemm: the LayerNorm fold (ln_stats) is a plain or GEGLU linear call: ln_cols + ln_parts, no bias / row vector / residual / activation / scales");
+            return fail(AA_E_SHAPE, "conv_gemm: the LayerNorm fold (ln_stats) is a plain or GEGLU linear call: ln_cols, no bias / row vector / residual / activation / scales");
     }
     if (d->row_stats && d->row_stats_parts != aa_conv_gemm_row_stats_parts(d))
         return fail(AA_E_SHAPE, "conv_gemm: row_stats_parts=%d, this call emits %d partial statistics per row (aa_conv_gemm_row_stats_parts)", d->row_stats_parts, aa_conv_gemm_row_stats_parts(d));
@@ -644,6 +646,15 @@ int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y, in
     else                 { if (sj == 1) AA_LN(bf16_t, 1); else if (sj == 2) AA_LN(bf16_t, 2); else AA_LN(bf16_t, 4); }
 #undef AA_LN
     return finish("layernorm");
+}
+
+int aa_ln_finalize(const float* stats, int32_t parts, float* coef, int64_t rows, int32_t channels, float eps, void* stream) {
+    using namespace aa;
+    if (!stats || !coef || parts <= 0 || rows <= 0 || channels <= 0) return fail(AA_E_SHAPE, "ln_finalize: rows=%lld parts=%d channels=%d", (long long)rows, parts, channels);
+    if (!aligned16(coef)) return fail(AA_E_ALIGN, "ln_finalize: coef must be 16-byte aligned");
+    const dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+    AA_LAUNCH(ln_finalize_kernel<0>, grid, block, 0, stream, stats, coef, rows, (int)parts, 1.0f / (float)channels, eps);
+    return finish("ln_finalize");
 }
 
 int aa_attention(const AaAttention* d, void* stream) {

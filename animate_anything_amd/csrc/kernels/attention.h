@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
 #pragma unroll
     for (int e = 0; e < 16; ++e) minus_m[e] = 0.0f;
 
+    const bool prio = (p._pad & 1) != 0;
     const int ntiles = (p.kv_len + KT - 1) / KT;
     const bool ragged = (p.kv_len & (KT - 1)) != 0;
     const int stages = attn_stages(p.kv_len);   // 3 (two tiles in flight ahead of the math) or 1 (single tile)
@@ -162,6 +163,7 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
             // S^T - m: the accumulators START at minus the running maximum (zero for the first tile) - the first MFMA of every
             // block takes a register set that holds -m in all 16 entries as its C operand, so no accumulator is initialised per tile
             f32x16 sacc[KB];
+            if (prio) wave_priority<1>();             // (experiment, AaAttention._pad bit 0: matrix clusters above the co-resident waves' softmax)
             // the two 32-key blocks alternate so that consecutive MFMAs never wait on each other's accumulator
 #pragma unroll
             for (int dk = 0; dk < 4; ++dk)
@@ -170,6 +172,7 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
                     const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + kb * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
                     sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], dk == 0 ? minus_m : sacc[kb]);
                 }
+            if (prio) wave_priority<0>();
             if (p.causal && kt * KT + KT - 1 > q0) {     // causal: keys after the query's own position (tiles that reach past the wave's first query)
                 const int qpos = q0 + ql;
 #pragma unroll
@@ -247,6 +250,7 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
             l_run += psum;
             // O^T += V^T P^T: chunk ch = 16 keys; this half-wave's 8 k-slots are keys 16ch + 4h + {0..3} and
             // 16ch + 8 + 4h + {0..3} (the order P^T's registers came out of the S^T accumulator layout)
+            if (prio) wave_priority<1>();
 #pragma unroll
             for (int ch = 0; ch < 2 * KB; ++ch)
 #pragma unroll
@@ -256,6 +260,7 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
                     const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
                     oacc[db] = mfma_32x32x16(T(), vf, pf[ch], oacc[db]);
                 }
+            if (prio) wave_priority<0>();
         }
     }
 

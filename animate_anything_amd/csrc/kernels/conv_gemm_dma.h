@@ -52,28 +52,27 @@ __host__ __device__ __forceinline__ int64_t cgd_out_row(const AaConvGemm& p, con
     return ((int64_t)img * (p.h_out * sy) + (y * sy + p.out_oy)) * (p.w_out * sx) + (x * sx + p.out_ox);
 }
 
-// LayerNorm folded into the consuming contraction (AaConvGemm.ln_stats): scale and offset of GEMM row m from the partial
-// (sum, sum of squares) pairs its producer left:  LN(x) W^T = a * (x W'^T) + nm * colsum(W') + b',  a = rstd, nm = -mean * rstd.
-struct LnRow { float a, nm; };
+// LayerNorm folded into the consuming contraction (AaConvGemm.ln_stats = per row (-mean, sqrt(var + eps), rstd, 0), written by
+// aa_ln_finalize from the producer's partial sums):  LN(x) W^T + b = a * (x W'^T) + nm * colsum(W') + b',  a = rstd, nm = -mean * rstd.
+struct LnRow { float a, nm, nmean, sd; };
+// rstd of a lane's row of every block row, handed from a kernel's accumulator start to its epilogue BY VALUE (a pointer to the
+// caller's array parks it in scratch)
+template <int MI> struct LnRstd { float v[MI]; bool on; };
 __device__ __forceinline__ LnRow cgd_ln_row(const AaConvGemm& p, const int m) {
-    const float* st = p.ln_stats + (int64_t)m * p.ln_parts * 2;
-    float s = 0.0f, q = 0.0f;
-    for (int t = 0; t < p.ln_parts; ++t) { s += st[2 * t]; q += st[2 * t + 1]; }
-    const float inv_c = 1.0f / (float)(p.c0 + p.c1);
-    const float mean = s * inv_c;
-    const float var = fmaxf(q * inv_c - mean * mean, 0.0f);
-    const float rstd = rsqrtf(var + p.ln_eps);
-    return LnRow{rstd, -mean * rstd};
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p.ln_stats + (int64_t)m * 4);
+    return LnRow{c[2], c[0] * c[2], c[0], c[1]};
 }
 
 template <typename T, int MI, int NI, bool GEGLU, bool RV, bool POST, bool BIAS, bool LNF, bool STATS, typename Get>
-__device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW, const int part,
-                                                  const float* sLn, const int ln_w) {
-    // sLn: LDS copy of colsum(W') [ln_w] and b' [ln_w] of this WAVE's columns (LNF only)
+__device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW, const int part, const LnRstd<MI> ln_rstd) {
+    // ln_rstd (LNF): rstd of this lane's row of every block row, still in the caller's registers from its accumulator start
     static_assert(!GEGLU || (NI % 2 == 0 && !RV && !POST), "GEGLU pairs value block j with gate block j + 1");
     static_assert(!LNF || (!RV && !POST && !BIAS && !STATS), "the LayerNorm fold covers the plain and the GEGLU form");
     static_assert(!STATS || !GEGLU, "row statistics: plain / residual forms");
     constexpr unsigned OOB = 0x80000000u;
+    // a column past the tensor's width: out of range of every descriptor used here (all shorter than 2^31 - 32 bytes), and - unlike
+    // OOB + OOB - still out of range when added to the OOB row offset of a scattered output grid (r04: 2^31 + 2^31 wrapped to 0)
+    constexpr unsigned COL_OOB = 0x7ffffff0u;
     constexpr int NJ = GEGLU ? NI / 2 : NI;                 // output blocks per block row
     const int lane = threadIdx.x & 63;
     const int ec = lane & 31, eh = lane >> 5;
@@ -94,7 +93,7 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int nc = (GEGLU ? (n_wave >> 1) : n_wave) + h * 32 + 16 * eh + 8 * q;
-            coff[h][q] = nc + 8 <= n_cols ? (unsigned)nc * 2u : OOB;
+            coff[h][q] = nc + 8 <= n_cols ? (unsigned)nc * 2u : COL_OOB;
         }
     // the row vector (else the residual) of a whole block row is fetched one block row AHEAD: a wave that is alone on its SIMD
     // has nothing else to run while a load is in flight
@@ -118,12 +117,11 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
         }
     };
     prefetch(IntTag<0>());
-    // LayerNorm fold: scale / offset of this lane's row of every block row; colsum(W') and b' of the wave's columns sit in LDS
-    // (sLn: [2][columns of the wave], fp32)
-    LnRow lnr[LNF ? MI : 1];
+    // LayerNorm fold: rstd of this lane's row of every block row
+    float ln_a[LNF ? MI : 1];
     if constexpr (LNF) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) lnr[i] = cgd_ln_row(p, min(m_wave + i * 32 + ec, M - 1));
+        for (int i = 0; i < MI; ++i) ln_a[i] = ln_rstd.on ? ln_rstd.v[i] : cgd_ln_row(p, min(m_wave + i * 32 + ec, M - 1)).a;
     }
     // row statistics of the STORED values (sum, sum of squares over this wave's columns) on the idle matrix pipe: with the two
     // 16-byte output packs of a block as the B operand, a ones fragment as A gives the row sums in every accumulator row, the
@@ -165,18 +163,10 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
                     for (int e = 0; e < 8; ++e) v[8 * q + e] += (float)r.e[e];
                 }
             }
-            auto ln_apply = [&](float (&x)[16], const int jj) __attribute__((always_inline)) {       // x = a * x + nm * colsum + b'
-              if constexpr (LNF) {
-                const int cw = jj * 32 + 16 * eh;                       // first of this lane's 16 columns, counted from n_wave
+            auto ln_apply = [&](float (&x)[16], const int) __attribute__((always_inline)) {       // the accumulation started from the fold's
+              if constexpr (LNF) {                                                                  // rank-1 terms (conv_gemm_x.h): x *= rstd
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    f32x4 cs, bb;
-                    // (LDS only: a select between an LDS and a global pointer here crashes hipcc 7.2's SimplifyCFG)
-                    cs = *reinterpret_cast<const f32x4*>(sLn + cw + 4 * q4);
-                    bb = *reinterpret_cast<const f32x4*>(sLn + ln_w + cw + 4 * q4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[4 * q4 + e] = fmaf(x[4 * q4 + e], lnr[i].a, fmaf(lnr[i].nm, cs[e], bb[e]));
-                }
+                for (int e = 0; e < 16; ++e) x[e] *= ln_a[i];
               }
             };
             if constexpr (LNF) ln_apply(v, j);
@@ -242,11 +232,11 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
 }
 
 // BIAS_FOLDED: the accumulators were started from the bias (conv_gemm_x.h) and sBiasW holds zeros.
-// part / sLn / ln_w: this wave's slot of AaConvGemm.row_stats (-1: the caller cannot emit them) and its LDS copy of the LayerNorm
-// fold's column vectors (cgd_epilogue_fast).
+// part: this wave's slot of AaConvGemm.row_stats (-1: the caller cannot emit them).  A BIAS_FOLDED caller has also started the
+// accumulators from the rank-1 terms of a folded LayerNorm (AaConvGemm.ln_stats): its epilogue form only scales by rstd.
 template <typename T, int MI, int NI, bool BIAS_FOLDED = false, typename Get>
 __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW,
-                                               const int part = -1, const float* sLn = nullptr, const int ln_w = 0) {
+                                               const int part = -1, const LnRstd<MI> ln_rstd = LnRstd<MI>{{}, false}) {
     // get(IntTag<i>, IntTag<j>) -> the 16 accumulators of 32x32 block (i, j) of this lane (an array element, or a read-out
     // of the literal accumulation registers of conv_gemm_x.h)
     const int lane = threadIdx.x & 63;
@@ -267,21 +257,21 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
     if (BIAS_FOLDED && !silu && !p.bias_per_row) {
         if (lnf) {
             if (p.geglu) {
-                if constexpr (NI % 2 == 0) { cgd_epilogue_fast<T, MI, NI, true, false, false, false, true, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w); return; }
-            } else { cgd_epilogue_fast<T, MI, NI, false, false, false, false, true, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w); return; }
+                if constexpr (NI % 2 == 0) { cgd_epilogue_fast<T, MI, NI, true, false, false, false, true, false>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd); return; }
+            } else { cgd_epilogue_fast<T, MI, NI, false, false, false, false, true, false>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd); return; }
         } else if (p.geglu) {
-            if constexpr (NI % 2 == 0) { if (!rowvec && !post) { cgd_epilogue_fast<T, MI, NI, true, false, false, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w); return; } }
+            if constexpr (NI % 2 == 0) { if (!rowvec && !post) { cgd_epilogue_fast<T, MI, NI, true, false, false, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd); return; } }
         } else if (rowvec) {
-            if (post) cgd_epilogue_fast<T, MI, NI, false, true, true, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
-            else cgd_epilogue_fast<T, MI, NI, false, true, false, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
+            if (post) cgd_epilogue_fast<T, MI, NI, false, true, true, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd);
+            else cgd_epilogue_fast<T, MI, NI, false, true, false, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd);
             return;
         } else if (stats) {
-            if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED, false, true>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
-            else cgd_epilogue_fast<T, MI, NI, false, false, false, !BIAS_FOLDED, false, true>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
+            if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED, false, true>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd);
+            else cgd_epilogue_fast<T, MI, NI, false, false, false, !BIAS_FOLDED, false, true>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd);
             return;
         } else {
-            if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
-            else cgd_epilogue_fast<T, MI, NI, false, false, false, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, sLn, ln_w);
+            if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd);
+            else cgd_epilogue_fast<T, MI, NI, false, false, false, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd);
             return;
         }
     }
@@ -296,7 +286,7 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
         const T* rv = rowvec ? rowvec + (int64_t)(mc / p.rowvec_div) * (p.rowvec_ld ? p.rowvec_ld : p.n_out) : nullptr;
         const T* rs = resid ? resid + (int64_t)mc * p.ldr : nullptr;
         const int64_t o_row_g = cgd_out_row(p, mc) * p.ldo;
-        const LnRow lr = lnf ? cgd_ln_row(p, mc) : LnRow{1.0f, 0.0f};
+        const LnRow lr = lnf ? cgd_ln_row(p, mc) : LnRow{1.0f, 0.0f, 0.0f, 1.0f};
         // one block-row of row-vector (or residual) pieces is fetched up front so their latency overlaps
         u32x4 pre[NI][2];
 #pragma unroll
@@ -336,7 +326,7 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
                 if (pre_is_rv) r.raw = pv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[q][e] = a[8 * q + e] + (float)b.e[e] + brow;
-                if (lnf) {                                // rstd * acc - rstd * mean * colsum(W') + b'  (general path: the vectors come from memory)
+                if (lnf && !BIAS_FOLDED) {                // rstd * acc - rstd * mean * colsum(W') + b'  (compiled tiles: nothing was folded into the start)
                     const float* cs = p.ln_cols + n_wave + j * 32 + 16 * eh + 8 * q;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[q][e] = fmaf(v[q][e], lr.a, fmaf(lr.nm, cs[e], cs[p.n_pad + e]));

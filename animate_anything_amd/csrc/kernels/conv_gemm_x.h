@@ -24,8 +24,12 @@
 
 namespace aa {
 
-// (+ the LayerNorm fold's column vectors of the tile: colsum(W') and b', fp32)
-__host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring) { return cgd_lds_bytes(bm, bn, bk, ring) + bn * 8; }
+// the tiles that can start their accumulators from a folded LayerNorm (one wave per SIMD, K step 64) keep a private copy of the two
+// column vectors of each wave's columns behind the bias slice: [wave][2][256] fp32 (an LDS-DMA piece deposits 1 KiB)
+__host__ __device__ constexpr bool cgx_ln_ok(int bk, int wm, int wn, int per_cu) { return wm * wn * per_cu <= 4 && bk == 64; }
+__host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring, int wm, int wn, int per_cu) {
+    return cgd_lds_bytes(bm, bn, bk, ring) + (cgx_ln_ok(bk, wm, wn, per_cu) ? wm * wn * 2048 : 0);
+}
 
 // DP3 / DP0 / DP1: LDS-DMA pieces (per wave) of the tile after next issued under sub-step 3 of a K step and under
 // sub-steps 0 / 1 of the following one (the rest under sub-step 2); activations first (they may come from HBM).
@@ -75,7 +79,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     char* smem = dyn_smem();
     char* dummy = smem + STAGES * STAGE_BYTES;
     T* sBias = reinterpret_cast<T*>(dummy + 1024);
-    float* sLn = reinterpret_cast<float*>(dummy + 2048);    // [2][BN]: AaConvGemm.ln_cols of this tile's columns (LayerNorm fold)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -264,23 +267,74 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     // their way.  Split-K partials and per-row biases start from zero (a descriptor of length 0 loads zeros).
     const bool bias_folded = k_splits == 1 && !p.bias_per_row;
     const BufRsrc r_bias = make_rsrc(p.bias, (p.bias && bias_folded) ? (unsigned)p.n_out * 2u : 0u);
+    // LayerNorm folded into this contraction (AaConvGemm.ln_stats):  out = rstd * (x W'^T - mean * colsum(W') + b' / rstd).  The
+    // bracket's two rank-1 terms are where the accumulation STARTS (2 VALU per accumulator, spent while the first operand stage is
+    // still on its way - in the epilogue the same arithmetic cost the K = 320 GEGLU / Q|K|V calls 15-20 %, r04d); the epilogue only
+    // multiplies by rstd.  Row m of block row i is this lane's row (lane & 31) in the accumulator layout.
+    // (one wave per SIMD only: the two-waves-per-SIMD tiles have 128 registers for everything outside the accumulators and would
+    // spill the prefetched column vectors; the host does not offer them a folded call - aa_conv_gemm_tile_ok)
+    constexpr bool LN_OK = cgx_ln_ok(BK, WM, WN, PER_CU);
+    const bool ln_start = LN_OK && p.ln_stats != nullptr && k_splits == 1;
+    // The row coefficients (16 bytes per row) are fetched HERE, with the bias and ahead of the first operand pieces; the column
+    // vectors of this wave's columns travel by LDS-DMA into a private LDS copy, as the OLDEST pieces of the wave: the counted
+    // wait in front of start_from_bias() covers them while the operand stages stay in flight (a global load issued where its value is
+    // needed costs a K = 320 tile 1-2 us of its ~13 - r04e: the fold lost 30 % on GEGLU / Q|K|V that way; prefetching into registers
+    // spills: 160 registers on the 320-column tiles).
+    constexpr int LNW = BN / WN;                         // columns of a wave
+    float* sLnW = reinterpret_cast<float*>(dummy + 2048) + wave * 512;
+    float ln_nmean[LN_OK ? MI : 1], ln_sd[LN_OK ? MI : 1], ln_rstd[LN_OK ? MI : 1];
     u32x4 bias_raw[NI][2];
+    if (!ln_start) {                     // (a folded call has no bias)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            bias_raw[j][q] = buf_load16(r_bias, (unsigned)(tile_n * BN + wn * (BN / WN) + j * 32 + 16 * (lane >> 5) + 8 * q) * 2u);
+            for (int q = 0; q < 2; ++q)
+                bias_raw[j][q] = buf_load16(r_bias, (unsigned)(tile_n * BN + wn * (BN / WN) + j * 32 + 16 * (lane >> 5) + 8 * q) * 2u);
+    }
+    if constexpr (LN_OK) if (ln_start) {
+        static_assert(!LN_OK || LNW * 4 <= 1024, "one LDS-DMA piece per column vector");
+        const BufRsrc r_ln = make_rsrc(p.ln_cols, (unsigned)(2 * p.n_pad) * 4u);
+        const unsigned c0b = (unsigned)(tile_n * BN + wn * LNW) * 4u + (unsigned)lane * 16u;
+        const bool in = lane * 4 < LNW;
+        async_copy16_buf(r_ln, in ? c0b : OOB, sLnW);                                       // colsum(W')
+        async_copy16_buf(r_ln, in ? c0b + (unsigned)p.n_pad * 4u : OOB, sLnW + 256);       // b' (each piece deposits 64 x 16 bytes)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const LnRow r = cgd_ln_row(p, min(m_begin + tile_m * BM + wm * (BM / WM) + i * 32 + (lane & 31), M - 1));
+            ln_nmean[i] = r.nmean; ln_sd[i] = r.sd; ln_rstd[i] = r.a;
+        }
+    }
     auto start_from_bias = [&]() __attribute__((always_inline)) {
         static_for<NI>([&](auto j_) __attribute__((always_inline)) {
             constexpr int j = decltype(j_)::value;
-            f32x16 b;
+            if (LN_OK && ln_start) {
+              if constexpr (LN_OK) {
+                f32x16 cs, bp;                                 // this lane's 16 columns of block j (the wave's own DMA: its counted wait suffices)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                Pack8<T> h; h.raw = bias_raw[j][q];
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(sLnW + j * 32 + 16 * (lane >> 5) + 4 * q4);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(sLnW + 256 + j * 32 + 16 * (lane >> 5) + 4 * q4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) b[8 * q + e] = (float)h.e[e];
+                    for (int e = 0; e < 4; ++e) { cs[4 * q4 + e] = c4[e]; bp[4 * q4 + e] = b4[e]; }
+                }
+                static_for<MI>([&](auto i_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(i_)::value;
+                    f32x16 v;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = fmaf(ln_nmean[i], cs[e], bp[e] * ln_sd[i]);
+                    acc_init<i * NI + j>(af, v);
+                });
+              }
+            } else {
+                f32x16 b;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    Pack8<T> h; h.raw = bias_raw[j][q];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b[8 * q + e] = (float)h.e[e];
+                }
+                static_for<MI>([&](auto i_) __attribute__((always_inline)) { acc_init<decltype(i_)::value * NI + j>(af, b); });
             }
-            static_for<MI>([&](auto i_) __attribute__((always_inline)) { acc_init<decltype(i_)::value * NI + j>(af, b); });
         });
     };
 
@@ -327,14 +381,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         substep(IntTag<3>(), IntTag<0>(), st_next, HAS_NEXT, IntTag<0>(), IntTag<HAS_NEXT2 ? DP3 : 0>(), BoolTag<HAS_NEXT2>());
     };
 
-    auto put_bias = [&]() __attribute__((always_inline)) {       // the general epilogue path adds a bias slice from LDS: zeros here, the
+    // YOUNGER = operand pieces this wave has issued since the fold's two column-vector pieces: those must have landed, these stay in flight
+    auto put_bias = [&](auto younger_) __attribute__((always_inline)) {       // the general epilogue path adds a bias slice from LDS: zeros here, the
         if (tid < BN / 8) *reinterpret_cast<u32x4*>(sBias + tid * 8) = u32x4{0u, 0u, 0u, 0u};     // accumulators already carry the bias
-        if (p.ln_cols) {                                         // (published by the K loop's barriers, like the bias slice)
-            for (int c = tid; c < 2 * BN; c += 64 * NW) {
-                const int half = c >= BN ? 1 : 0, col = tile_n * BN + c - half * BN;
-                sLn[c] = col < p.n_pad ? p.ln_cols[(int64_t)half * p.n_pad + col] : 0.0f;
-            }
-        }
+        if constexpr (LN_OK) { if (ln_start) { dma_wait<decltype(younger_)::value>(); wave_sync(); } }      // (the pieces were deposited by all lanes of this wave)
         start_from_bias();
     };
     if constexpr (BK == 64) {
@@ -344,7 +394,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             dma_range(IntTag<0>(), IntTag<PER_TILE>());
             if (nk > 1) { prepare(1, 1); dma_range(IntTag<0>(), IntTag<DP3>()); }
             fragment_offsets();
-            put_bias();
+            if (nk > 1) put_bias(IntTag<PER_TILE + DP3>()); else put_bias(IntTag<PER_TILE>());
             if (nk > 1) dma_wait<DP3>(); else dma_wait<0>();
             block_barrier();
             stamp(6);
@@ -355,7 +405,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             if (nk >= 2) { kstep(kt, BoolTag<true>(), BoolTag<false>()); ++kt; }
             kstep(kt, BoolTag<false>(), BoolTag<false>());
         } else {
-            put_bias();
+            put_bias(IntTag<0>());
             __syncthreads();
         }
     } else {
@@ -386,7 +436,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             });
             if (nk > RING - 1) { prepare(RING - 1, RING - 1); dma_range(IntTag<0>(), IntTag<DPB>()); }
             fragment_offsets();
-            put_bias();
+            put_bias(IntTag<0>());                                      // (deep-ring tiles carry no folded LayerNorm: cgx_ln_ok)
             if (nk > RING - 1) dma_wait<(RING - 2) * PER_TILE + DPB>();
             else if (RING == 4 && nk == 3) dma_wait<2 * PER_TILE>();
             else if (nk >= 2) dma_wait<PER_TILE>();                     // (nk == 2, or RING == 3 and nk == 2)
@@ -408,10 +458,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
             }
             stage_step(s, BoolTag<false>(), BoolTag<false>(), BoolTag<false>(), IntTag<0>());
         } else {
-            put_bias();
+            put_bias(IntTag<0>());
             __syncthreads();
         }
     }
+    LnRstd<MI> ln_scale;
+    ln_scale.on = ln_start;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) ln_scale.v[i] = LN_OK ? ln_rstd[LN_OK ? i : 0] : 1.0f;
     acc_settle();                                                // MFMA results visible to v_accvgpr_read
     stamp(2);
     if constexpr (PER_CU > 1) wave_priority<0>();
@@ -438,7 +492,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     }
     cgd_epilogue_g<T, MI, NI, true>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) { return acc_get<decltype(i_)::value * NI + decltype(j_)::value>(af); },
                               m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN),
-                              p.row_stats ? tile_n * WN + wn : -1, p.ln_cols ? sLn + wn * (BN / WN) : nullptr, BN);
+                              p.row_stats ? tile_n * WN + wn : -1, ln_scale);
     stamp(5);
     stamp_wall(4, -1);
 }

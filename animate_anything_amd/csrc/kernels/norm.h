@@ -337,6 +337,22 @@ __global__ void __launch_bounds__(GNF_THREADS, NR <= 16 ? 4 : 2) groupnorm_fused
 }
 
 // ---- LayerNorm: a wavefront owns LN_ROWS<SJ> rows at a time, the rows live in registers (C <= 2048), two-pass variance.
+// LayerNorm fold, between producer and consumer: the partial (sum, sum of squares) pairs a contraction left per output row
+// (AaConvGemm.row_stats) -> per row (-mean, sqrt(var + eps), rstd, 0): what the consuming contraction starts its accumulators from
+// and scales by (AaConvGemm.ln_stats).  One thread per row; 8 * parts + 16 bytes per row.
+template <int UNIT = 0>          // (a template only so that the header may be included by several translation units)
+__global__ void __launch_bounds__(256) ln_finalize_kernel(const float* stats, float* coef, int64_t rows, int parts, float inv_c, float eps) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows) return;
+    const float* st = stats + m * parts * 2;
+    float s = 0.0f, q = 0.0f;
+    for (int t = 0; t < parts; ++t) { s += st[2 * t]; q += st[2 * t + 1]; }
+    const float mean = s * inv_c;
+    const float var = fmaxf(q * inv_c - mean * mean, 0.0f);
+    const float sd = sqrtf(var + eps);
+    *reinterpret_cast<f32x4*>(coef + m * 4) = f32x4{-mean, sd, 1.0f / sd, 0.0f};
+}
+
 // SJ = 16-byte slots per lane and row (C <= 512 * SJ); narrow rows are processed several at once so that every wave
 // keeps four independent 16-byte loads in flight (a 640-byte row per wave leaves HBM latency exposed).
 template <typename T, int SJ>

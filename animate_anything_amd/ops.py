@@ -32,6 +32,7 @@ LAST_STAMPS = None
 GN_PLANS = None            # a list: groupnorm() appends (groups per workgroup, pieces per thread, parts, grid) or None per call
 MAX_OPERAND_BYTES = 1 << 31      # the contraction kernel's 32-bit operand offsets
 FORCE_TILE = -1       # tests / sweeps: >= 0 puts this tile-table index into AaConvGemm.tile of every conv_gemm call (strict: ineligible = error)
+ATTN_FLAGS = 0        # experiments: AaAttention._pad (bit 0: s_setprio 1 around the matrix clusters of the head_dim-64 kernel)
 K_SPLITS = 0          # tests: explicit K split count for calls that are not autotuned (0 = library decides)
 DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
 class _TileTable:
@@ -373,10 +374,20 @@ def pack_upsample2x_weights(weight: torch.Tensor, bias: Optional[torch.Tensor] =
 @dataclass
 class RowStats:
     """Partial (sum, sum of squares) per row of a token matrix, [rows, parts, 2] fp32, left by the contraction that wrote it
-    (AaConvGemm.row_stats) for the contraction that folds the LayerNorm of that matrix (AaConvGemm.ln_stats)."""
+    (AaConvGemm.row_stats); `coef(channels, eps)` turns them (aa_ln_finalize, once) into the per-row (-mean, sqrt(var + eps),
+    rstd, 0) that the contraction folding the LayerNorm of that matrix takes (AaConvGemm.ln_stats)."""
     data: torch.Tensor
     rows: int
     parts: int
+    _coef: Optional[torch.Tensor] = None
+    _coef_key: tuple = ()
+
+    def coef(self, channels, eps):
+        if self._coef is None or self._coef_key != (channels, eps):
+            out = torch.empty(self.rows, 4, dtype=torch.float32, device=self.data.device)
+            _run(_lib.get().aa_ln_finalize, _ptr(self.data), self.parts, _ptr(out), self.rows, channels, float(eps), _stream(self.data))
+            self._coef, self._coef_key = out, (channels, eps)
+        return self._coef
 
     def repeat(self, n):
         return RowStats(torch.cat([self.data] * n), self.rows * n, self.parts)
@@ -495,7 +506,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     if ln_stats is not None:
         if pw.ln_cols is None or ln_stats.rows != g.rows:
             raise RuntimeError("conv_gemm: ln_stats needs weights packed with a folded LayerNorm and statistics of every row of x0")
-        d.ln_stats, d.ln_cols, d.ln_parts, d.ln_eps = _ptr(ln_stats.data), _ptr(pw.ln_cols), ln_stats.parts, pw.ln_eps
+        d.ln_stats, d.ln_cols = _ptr(ln_stats.coef(c0, pw.ln_eps)), _ptr(pw.ln_cols)
     elif pw.ln_cols is not None:
         raise RuntimeError("conv_gemm: these weights carry a folded LayerNorm: pass the row statistics of x0 (ln_stats)")
     if acc_scale == 0.0:
@@ -503,7 +514,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     d.k_order = pw.k_order
     d.debug = DEBUG_ABLATE
     d.tile, d.k_splits = -1, K_SPLITS
-    if AUTOTUNE and x0.is_cuda:
+    if AUTOTUNE and x0.is_cuda and FORCE_TILE < 0 and K_SPLITS == 0:      # (explicit tile / split requests of tests and sweeps are not re-tuned)
         key = (d.dtype, g.n_img, g.h_in, g.w_in, d.h_virt, d.w_virt, g.h_out, g.w_out, g.stride, pw.kh, pw.kw, c0, c1,
                pw.n_out, d.geglu, residual is not None) + (("ln",) if ln_stats is not None else ()) + (("stats",) if row_stats else ())
         _load_default_tile_cache()
@@ -612,6 +623,7 @@ def attention(q: torch.Tensor, q_col0: int, k: torch.Tensor, k_col0: int, v: tor
     d.o = _operand(out, 0, *q_strides)
     d.k.seq_mod = d.v.seq_mod = kv_seq_mod       # > 0: sequence number n reads K / V table entry n % kv_seq_mod
     d.causal = int(causal)                       # key position > query position masked (CLIP text encoder)
+    d._pad = ATTN_FLAGS
     d.n_outer, d.n_inner, d.heads, d.head_dim = n_outer, n_inner, heads, head_dim
     d.q_len, d.kv_len, d.dtype = q_len, kv_len, _DT[q.dtype]
     d.scale = float(head_dim) ** -0.5 if scale is None else scale

@@ -218,11 +218,15 @@ class StableVideoDiffusionPipeline:
         # half-precision STORAGE with fp32 accumulation, so the guard here is: fp16 first; if anything overflowed, once more with
         # bf16 storage (fp32's exponent range).  One host sync per clip.
         if (self.vae.dtype == torch.float16 and getattr(self.vae.config, "force_upcast", False) and not bool(torch.isfinite(lat).all())):
-            self.vae.to(torch.bfloat16)
-            try:
-                lat = self.vae.encode(image.to(device, torch.bfloat16)).latent_dist.mode().to(torch.float16)
-            finally:
-                self.vae.to(torch.float16)
+            # the retry runs on a bf16 COPY of the encoder half: the live fp16 parameters are never touched (an in-place
+            # fp16 -> bf16 -> fp16 round trip would leave every weight rounded to 8 mantissa bits for the rest of the pipeline's life
+            # and re-pack every weight cache twice)
+            import copy
+            enc = copy.copy(self.vae)                           # shallow: shares config and the (unused here) decoder
+            enc._modules = dict(self.vae._modules)
+            enc._modules["encoder"] = copy.deepcopy(self.vae.encoder).to(torch.bfloat16)
+            enc._modules["quant_conv"] = copy.deepcopy(self.vae.quant_conv).to(torch.bfloat16)
+            lat = enc.encode(image.to(device, torch.bfloat16)).latent_dist.mode().to(torch.float16)
         if do_classifier_free_guidance:
             lat = torch.cat([torch.zeros_like(lat), lat])
         return lat.repeat(num_videos_per_prompt, 1, 1, 1)

@@ -214,7 +214,7 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
             "whole_step_frac_of_peak": round(flop_step / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
 
 
-def respawn_under_torchrun(a):
+def respawn_under_torchrun(a, script):
     """`python bench.py --gpus N` (N > 1) outside torchrun: start N ranks on this node, one per GPU."""
     import socket
     import subprocess
@@ -222,7 +222,7 @@ def respawn_under_torchrun(a):
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     raise SystemExit(subprocess.call(cmd, env=env))
 
@@ -376,24 +376,14 @@ def run_svd(a, rank, world, device):
     print(json.dumps(out), flush=True)
 
 
-def selftest_library():
-    """AA_BENCH_SELFTEST=1 (tests/test_bench_multirank.py only): the N > 1 CONTROL FLOW of this script - respawn under torchrun,
-    rank / WORLD_SIZE checks, clip ownership and seeds, barriers, the gather inside the timed region, max over ranks, the one
-    JSON line of rank 0 - on CPU ranks over gloo, with the test suite's CPU build of the same kernel sources (tests/emu) and a toy
-    architecture.  The line it prints says "selftest" and is not a measurement; without the variable there is no CPU path."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
-    import build_emu
-    from animate_anything_amd import _lib
-    return _lib.use_library(_lib.bind(build_emu.build()), host_pointers=True)
-
-
-def main():
+def main(selftest_library=None, script=None):
+    """`selftest_library` / `script`: tests/bench_selftest.py drives this script's N > 1 control flow on CPU ranks (gloo, the test
+    suite's CPU build of the kernels, a toy architecture; the line it prints says "selftest" and is not a measurement) by passing
+    a context manager that swaps the library and its own path for the torchrun respawn.  bench.py itself knows no CPU path."""
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        respawn_under_torchrun(a)
-    selftest = os.environ.get("AA_BENCH_SELFTEST") == "1"
-    if selftest:
+        respawn_under_torchrun(a, script or os.path.abspath(__file__))
+    if selftest_library is not None:
         with selftest_library():
             return bench(a, selftest=True)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"

@@ -108,10 +108,10 @@ typedef struct AaConvGemm {
      * norm2 -> to_q, norm3 -> GEGLU.proj; the LayerNorm kernel and the normalised tensor disappear).  With W' = W diag(gamma):
      *   LN(x) W^T + b  =  rstd[m] * (x W'^T)[m, n]  -  rstd[m] * mean[m] * colsum(W')[n]  +  (b + beta W^T)[n]
      * The row statistics come from the epilogue of the contraction that PRODUCED x (row_stats). */
-    const float* ln_stats;  /* consumer: [M][ln_parts][2] fp32 partial (sum, sum of squares) of each row of the A operand; NULL = no fold */
+    const float* ln_stats;  /* consumer: [M][4] fp32 per row of the A operand: (-mean, sqrt(var + eps), rstd, 0) - aa_ln_finalize's output; NULL = no fold */
     const float* ln_cols;   /* consumer: [2][n_pad] fp32: colsum(W')[n], then (b + beta W^T)[n]; `bias` must be NULL */
-    int32_t ln_parts;
-    float ln_eps;
+    int32_t ln_parts;       /* reserved: 0 */
+    float ln_eps;           /* reserved */
     float* row_stats;       /* producer: [M][row_stats_parts][2] fp32: (sum, sum of squares) of the stored output row over the columns of
                                one wave of the tile - written iff row_stats_parts == aa_conv_gemm_row_stats_parts(d) > 0 */
     int32_t row_stats_parts;
@@ -129,6 +129,10 @@ int aa_conv_gemm_launch_count(const AaConvGemm* d);
  * 0 when the way it carries the call out cannot emit them (compiled tiles, K splits, a split-off last round) - the caller then runs
  * the LayerNorm it wanted to fold as a kernel. */
 int aa_conv_gemm_row_stats_parts(const AaConvGemm* d);
+/* Between the two (version 105): stats [rows][parts][2] fp32 partial (sum, sum of squares) over `channels` values per row ->
+ * coef [rows][4] fp32 = (-mean, sqrt(var + eps), rstd, 0), the `ln_stats` operand of the consuming aa_conv_gemm
+ * (torch.nn.LayerNorm statistics: biased variance; reference use: diffusers BasicTransformerBlock.norm1 / norm2 / norm3). */
+int aa_ln_finalize(const float* stats, int32_t parts, float* coef, int64_t rows, int32_t channels, float eps, void* stream);
 
 /* Tile table of the LDS-DMA contraction kernel (what `AaConvGemm.tile` indexes): fills info[0..6] = rows, columns, wave
  * rows, wave columns, K step, ring stages, workgroups per CU of entry `idx`; returns 0, or -1 past the end of the table. */

@@ -45,6 +45,7 @@ CFGS = list(ops.TILE_TABLE)
 ONLY_CFGS = {int(c) for c in a.cfgs.split(",") if c}
 ops.AUTOTUNE = False
 ops.DEBUG_ABLATE = a.ablate
+ops.ATTN_FLAGS = int(os.environ.get("AA_ATTN_FLAGS", "0"))
 
 
 def sweep(name, fn, flops, n_pad, geglu=0):

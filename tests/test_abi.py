@@ -120,8 +120,9 @@ def test_x_kernels_keep_hipcc_out_of_the_accumulators(tmp_path):
         body = "\n".join(bodies[name])
         literal_blocks = agpr // 16
         assert literal_blocks in (4, 8, 12, 15, 16), (name, agpr)
-        # the accumulators are written by the source only: started from the bias at two sites (K loop prologue, empty K range)
-        assert len(re.findall(r"v_accvgpr_write", body)) == 2 * 16 * literal_blocks, name
+        # the accumulators are written by the source only: started from the bias (or a folded LayerNorm's terms) at the K loop prologue / empty K range
+        writes = len(re.findall(r"v_accvgpr_write", body))        # (r04: the BK = 64 prologue has two sites (one or more K steps), tiles that can start
+        assert writes % (16 * literal_blocks) == 0 and 2 <= writes // (16 * literal_blocks) <= 8, (name, writes)      #  from a folded LayerNorm two forms per site)
         # read-out sites (split-K partials, the general epilogue, its branch-free forms) read every block exactly once each
         reads = len(re.findall(r"v_accvgpr_read", body))
         assert 2 * 16 * literal_blocks <= reads <= 16 * 16 * literal_blocks, (name, reads)     # (r04: + LayerNorm-fold / row-statistics forms; hipcc may clone part of a form)

@@ -1,8 +1,8 @@
 """bench.py's N > 1 control flow on CPU: `python bench.py --gpus 2` respawns itself under torch.distributed.run, the two ranks
 check WORLD_SIZE, own one clip each (different seeds), run the real denoising loop, gather the final latents inside the timed
-region, take the max over ranks and rank 0 prints ONE JSON line.  AA_BENCH_SELFTEST=1 swaps RCCL for gloo, the GPU library for the
-test suite's CPU build of the same kernels and the 1.4 G-parameter architecture for a toy one - nothing else; the line says so.
-Without the variable the script refuses to run on a machine without GPUs."""
+region, take the max over ranks and rank 0 prints ONE JSON line.  tests/bench_selftest.py calls bench.main() with RCCL swapped for
+gloo, the GPU library for the test suite's CPU build of the same kernels and the 1.4 G-parameter architecture for a toy one -
+nothing else; the line says so.  bench.py itself refuses to run on a machine without GPUs."""
 import json
 import os
 import subprocess
@@ -13,14 +13,14 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, env_extra, timeout=600):
+def _run(args, env_extra, timeout=600, script="tests/bench_selftest.py"):
     env = dict(os.environ, AA_EMU_THREADS="2", OMP_NUM_THREADS="2", **env_extra)
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env,
+    return subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, capture_output=True, text=True, env=env,
                           timeout=timeout, cwd=ROOT)
 
 
 def test_two_ranks_through_the_script_itself():
-    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"AA_BENCH_SELFTEST": "1"})
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], {})
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                     # rank 0 only, exactly one line
@@ -35,13 +35,14 @@ def test_two_ranks_through_the_script_itself():
 
 
 def test_world_size_mismatch_is_refused():
-    env = {"AA_BENCH_SELFTEST": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}
+    env = {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
 
 
-def test_no_cpu_path_without_the_selftest_variable():
+def test_bench_itself_has_no_cpu_path():
     if torch.cuda.is_available():
         return
-    r = _run(["--steps", "1", "--warmup", "0"], {})
+    assert "tests" not in [ln.split()[-1].strip('"\',)') for ln in open(os.path.join(ROOT, "bench.py")) if "sys.path" in ln]
+    r = _run(["--steps", "1", "--warmup", "0"], {}, script="bench.py")
     assert r.returncode != 0 and "no CPU fallback" in r.stderr

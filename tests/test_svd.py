@@ -375,3 +375,32 @@ def test_variant_checkpoints_and_callback_latents(tmp_path):
     for k, v in vae.state_dict().items():
         assert torch.equal(v, again.state_dict()[k])
     assert set(load_state(str(d), "diffusion_pytorch_model", "fp16").keys()) == set(vae.state_dict().keys())
+
+
+def test_vae_overflow_retry_leaves_the_fp16_weights_untouched(emu, monkeypatch):
+    """the bf16 retry of `_encode_vae_image` (the reference upcasts to fp32 under `force_upcast`, models/pipeline.py:373-383)
+    runs on a copy of the encoder - the live fp16 VAE parameters are bit-identical afterwards and the result is a finite latent."""
+    _, net_v = tiny_vae()
+    before = {k: v.clone() for k, v in net_v.state_dict().items()}
+    pipe = MaskStableVideoDiffusionPipeline(net_v, None, None, EulerDiscreteScheduler())
+    image = torch.rand(1, 3, 8, 8, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    cls = type(net_v)
+    real, calls = cls.encode, []
+
+    def encode(self, x):
+        out = real(self, x)
+        calls.append(x.dtype)
+        if len(calls) == 1:                                      # the fp16 pass "overflows"
+            out.latent_dist.mean[...] = float("inf")
+        return out
+    monkeypatch.setattr(cls, "encode", encode)
+    with torch.no_grad():
+        lat = pipe._encode_vae_image(image.half(), torch.device("cpu"), 1, True)
+    assert calls == [torch.float16, torch.bfloat16]
+    assert lat.dtype == torch.float16 and torch.isfinite(lat).all() and lat.shape[0] == 2 and (lat[0] == 0).all()
+    after = net_v.state_dict()
+    assert all(after[k].dtype == before[k].dtype and torch.equal(after[k], before[k]) for k in before)
+    monkeypatch.setattr(cls, "encode", real)
+    with torch.no_grad():
+        want = net_v.encode(image.half()).latent_dist.mode()
+    assert rel_err(lat[1:], want) < 3e-2                         # bf16 storage against fp16 storage
