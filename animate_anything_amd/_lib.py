@@ -29,7 +29,7 @@ class AaConvGemm(C.Structure):
         ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("k_order", C.c_int32), ("debug", C.c_int32), ("tile", C.c_int32), ("k_splits", C.c_int32), ("rowvec_ld", C.c_int32), ("acc_scale", C.c_float),
         ("out_sy", C.c_int32), ("out_sx", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_cols", C.c_void_p), ("ln_parts", C.c_int32), ("ln_eps", C.c_float),
-        ("row_stats", C.c_void_p), ("row_stats_parts", C.c_int32), ("_pad105", C.c_int32),
+        ("row_stats", C.c_void_p), ("row_stats_parts", C.c_int32), ("tickets_len", C.c_int32), ("tickets", C.c_void_p),
     ]
 
 
@@ -109,7 +109,7 @@ class AaEulerStepTok(C.Structure):
     ]
 
 
-SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_conv_gemm_row_stats_parts", "aa_ln_finalize", "aa_groupnorm_workspace", "aa_groupnorm", "aa_set_groupnorm_two_pass", "aa_groupnorm_plan",
+SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_conv_gemm_row_stats_parts", "aa_conv_gemm_tickets", "aa_conv_gemm_reduce_launches", "aa_conv_gemm_tile_flags", "aa_ln_finalize", "aa_groupnorm_workspace", "aa_groupnorm", "aa_set_groupnorm_two_pass", "aa_groupnorm_plan",
            "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step",
            "aa_timestep_embedding", "aa_pack_latents", "aa_cfg_dpm_step_tokens",
            "aa_blend", "aa_pack_frames", "aa_cfg_euler_step_tokens")
@@ -140,6 +140,9 @@ def bind(path: str) -> C.CDLL:
     lib.aa_conv_gemm_row_stats_parts.argtypes = [C.POINTER(AaConvGemm)]
     lib.aa_conv_gemm_row_stats_parts.restype = C.c_int
     lib.aa_conv_gemm_launch_count.argtypes = [C.POINTER(AaConvGemm)]
+    lib.aa_conv_gemm_tickets.argtypes = [C.POINTER(AaConvGemm)]
+    lib.aa_conv_gemm_reduce_launches.argtypes = [C.POINTER(AaConvGemm)]
+    lib.aa_conv_gemm_tile_flags.argtypes = [C.c_int]
     lib.aa_set_groupnorm_two_pass.argtypes = [C.c_int]
     lib.aa_set_groupnorm_two_pass.restype = None
     lib.aa_groupnorm_plan.argtypes = [C.POINTER(AaGroupNorm), C.POINTER(C.c_int32)]

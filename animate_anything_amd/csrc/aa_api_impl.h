@@ -39,7 +39,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tile configurations of the LDS-DMA contraction kernel.  `rate` is the relative throughput of a tile
 // shape once the CUs are full (measured: the L2 -> LDS stream limits the narrow tiles); the chooser
 // minimises rounds(tiles / resident slots) * tile work / rate over the shapes that divide the packed width.
-struct CgCfg { int bm, bn, wm, wn, bk, stages, per_cu; float rate; int slab = 0; int x = 0; };   // slab: conv_slab.h (3x3 stride-1 halo-slab kernel); x: conv_gemm_x.h
+// slab: conv_slab.h (3x3 stride-1 halo-slab kernel); x: conv_gemm_x.h; sched: what else tells two entries of one shape apart
+// (aa_conv_gemm_tile_flags) - bit 0 staggered, bit 1 spread DMA issue of the compiled kernel, bits 6.. DP3 | DP0 << 4 | DP1 << 8
+struct CgCfg { int bm, bn, wm, wn, bk, stages, per_cu; float rate; int slab = 0; int x = 0; int sched = 0; };
+constexpr int cg_dp(int dp3, int dp0, int dp1) { return (dp3 | dp0 << 4 | dp1 << 8) << 6; }
 static const CgCfg kCgCfgs[] = {
     {128, 64, 2, 2, 64, 2, 3, 0.78f},     // 0
     {128, 128, 2, 2, 64, 2, 2, 0.90f},    // 1
@@ -55,51 +58,51 @@ static const CgCfg kCgCfgs[] = {
     {128, 320, 2, 2, 32, 2, 2, 1.10f},    // 11 two independent 4-wave workgroups per CU (phases de-synchronise)
     {128, 256, 2, 2, 32, 2, 2, 1.05f},    // 12
     {128, 256, 2, 2, 64, 2, 1, 1.00f},    // 13
-    {256, 320, 4, 2, 64, 2, 1, 1.30f},    // 14 staggered: the second wave of every SIMD multiplies before it issues its DMA share
-    {256, 256, 4, 2, 64, 2, 1, 1.25f},    // 15 staggered
+    {256, 320, 4, 2, 64, 2, 1, 1.30f, 0, 0, 1},    // 14 staggered: the second wave of every SIMD multiplies before it issues its DMA share
+    {256, 256, 4, 2, 64, 2, 1, 1.25f, 0, 0, 1},    // 15 staggered
     {128, 128, 2, 2, 32, 2, 3, 0.90f},    // 16 three small-LDS workgroups per CU
     {128, 64, 2, 2, 32, 2, 4, 0.78f},     // 17 four per CU
     {64, 128, 2, 2, 32, 2, 4, 0.70f},     // 18 short tiles for the small-M levels (more workgroups)
     {64, 64, 2, 2, 32, 2, 6, 0.60f},      // 19
     {64, 256, 2, 2, 32, 2, 3, 0.80f},     // 20
-    {256, 320, 4, 2, 32, 4, 1, 1.20f},    // 21 staggered, deep ring
-    {256, 256, 4, 2, 32, 4, 1, 1.20f},    // 22 staggered, deep ring
+    {256, 320, 4, 2, 32, 4, 1, 1.20f, 0, 0, 1},    // 21 staggered, deep ring
+    {256, 256, 4, 2, 32, 4, 1, 1.20f, 0, 0, 1},    // 22 staggered, deep ring
     {192, 256, 2, 4, 64, 2, 1, 1.05f},    // 23 eight waves of 96x64: 230 tiles for the 8704-row (16x16) level = one 90 % round
-    {192, 256, 2, 4, 64, 2, 1, 1.05f},    // 24 staggered
+    {192, 256, 2, 4, 64, 2, 1, 1.05f, 0, 0, 1},    // 24 staggered
     {128, 256, 2, 4, 32, 2, 2, 1.00f},    // 25 eight waves of 64x64, two workgroups per CU
     // "spread": every wave issues its DMA share of the next tile in pieces in front of the k sub-steps of its multiply
-    {256, 320, 4, 2, 64, 2, 1, 1.30f},    // 26 spread
-    {256, 256, 4, 2, 64, 2, 1, 1.25f},    // 27 spread
-    {192, 256, 2, 4, 64, 2, 1, 1.05f},    // 28 spread
-    {256, 320, 4, 2, 32, 4, 1, 1.20f},    // 29 spread, deep ring
-    {128, 320, 2, 2, 32, 2, 2, 1.10f},    // 30 spread, two workgroups per CU
-    {128, 128, 2, 2, 64, 2, 2, 0.90f},    // 31 spread
-    {192, 320, 3, 2, 64, 2, 1, 1.05f},    // 32 spread
-    {128, 256, 2, 2, 32, 2, 2, 1.05f},    // 33 spread
+    {256, 320, 4, 2, 64, 2, 1, 1.30f, 0, 0, 2},    // 26 spread
+    {256, 256, 4, 2, 64, 2, 1, 1.25f, 0, 0, 2},    // 27 spread
+    {192, 256, 2, 4, 64, 2, 1, 1.05f, 0, 0, 2},    // 28 spread
+    {256, 320, 4, 2, 32, 4, 1, 1.20f, 0, 0, 2},    // 29 spread, deep ring
+    {128, 320, 2, 2, 32, 2, 2, 1.10f, 0, 0, 2},    // 30 spread, two workgroups per CU
+    {128, 128, 2, 2, 64, 2, 2, 0.90f, 0, 0, 2},    // 31 spread
+    {192, 320, 3, 2, 64, 2, 1, 1.05f, 0, 0, 2},    // 32 spread
+    {128, 256, 2, 2, 32, 2, 2, 1.05f, 0, 0, 2},    // 33 spread
     // halo-slab 3x3 kernel (conv_slab.h): the activations of a 32-channel unit are staged once for all nine taps
     {256, 320, 4, 2, 32, 3, 1, 1.00f, 1}, // 34
     {256, 256, 4, 2, 32, 3, 1, 1.00f, 1}, // 35
     // hand-placed instruction stream, accumulators in a[0:255] (conv_gemm_x.h): one wave per SIMD, 128x128 / 128x160 per wave
-    {256, 256, 2, 2, 64, 2, 1, 1.45f, 0, 1}, // 36 DMA pieces of the tile after next under sub-steps 3 / 0 (8 + 8)
-    {256, 320, 2, 2, 64, 2, 1, 1.45f, 0, 1}, // 37 (11 + 7)
-    {256, 256, 2, 2, 64, 2, 1, 1.40f, 0, 1}, // 38 pieces spread over sub-steps 3 / 0 / 1 (6 + 5 + 5)
-    {256, 320, 2, 2, 64, 2, 1, 1.40f, 0, 1}, // 39 (7 + 6 + 5)
+    {256, 256, 2, 2, 64, 2, 1, 1.45f, 0, 1, cg_dp(8, 8, 0)}, // 36 DMA pieces of the tile after next under sub-steps 3 / 0 (8 + 8)
+    {256, 320, 2, 2, 64, 2, 1, 1.45f, 0, 1, cg_dp(11, 7, 0)}, // 37 (11 + 7)
+    {256, 256, 2, 2, 64, 2, 1, 1.40f, 0, 1, cg_dp(6, 5, 5)}, // 38 pieces spread over sub-steps 3 / 0 / 1 (6 + 5 + 5)
+    {256, 320, 2, 2, 64, 2, 1, 1.40f, 0, 1, cg_dp(7, 6, 5)}, // 39 (7 + 6 + 5)
     // the same stream with two waves per SIMD (64x128 per wave)
-    {256, 256, 4, 2, 64, 2, 1, 1.35f, 0, 1}, // 40
+    {256, 256, 4, 2, 64, 2, 1, 1.35f, 0, 1, cg_dp(2, 2, 2)}, // 40
     // deep ring: four stages of 32 K, three of them in flight, counted waits (conv_gemm_x.h "BK = 32")
-    {256, 256, 2, 2, 32, 4, 1, 1.50f, 0, 1}, // 41 one wave per SIMD
-    {256, 320, 2, 2, 32, 4, 1, 1.50f, 0, 1}, // 42
-    {256, 256, 4, 2, 32, 4, 1, 1.45f, 0, 1}, // 43 two waves per SIMD
+    {256, 256, 2, 2, 32, 4, 1, 1.50f, 0, 1, cg_dp(4, 0, 0)}, // 41 one wave per SIMD
+    {256, 320, 2, 2, 32, 4, 1, 1.50f, 0, 1, cg_dp(5, 0, 0)}, // 42
+    {256, 256, 4, 2, 32, 4, 1, 1.45f, 0, 1, cg_dp(2, 0, 0)}, // 43 two waves per SIMD
     // two 4-wave workgroups per CU (64x128 per wave, a[0:127]), three-slot ring: one multiplies while the other is in its epilogue
-    {128, 256, 2, 2, 32, 3, 2, 1.20f, 0, 1}, // 44
-    {256, 128, 4, 1, 32, 3, 2, 1.20f, 0, 1}, // 45
+    {128, 256, 2, 2, 32, 3, 2, 1.20f, 0, 1, cg_dp(3, 0, 0)}, // 44
+    {256, 128, 4, 1, 32, 3, 2, 1.20f, 0, 1, cg_dp(3, 0, 0)}, // 45
     // the shapes the 34 x 16 x 16 and 34 x 8 x 8 levels (8704 / 2176 rows) fill the chip with
-    {192, 256, 2, 2, 64, 2, 1, 1.30f, 0, 1}, // 46 one wave per SIMD, 96x128 per wave (a[0:191])
-    {128, 128, 2, 2, 64, 2, 2, 1.00f, 0, 1}, // 47 two 4-wave workgroups per CU, 64x64 per wave (a[0:63])
-    {128, 128, 2, 2, 32, 4, 2, 1.00f, 0, 1}, // 48 the same on the deep ring
+    {192, 256, 2, 2, 64, 2, 1, 1.30f, 0, 1, cg_dp(5, 5, 4)}, // 46 one wave per SIMD, 96x128 per wave (a[0:191])
+    {128, 128, 2, 2, 64, 2, 2, 1.00f, 0, 1, cg_dp(2, 2, 2)}, // 47 two 4-wave workgroups per CU, 64x64 per wave (a[0:63])
+    {128, 128, 2, 2, 32, 4, 2, 1.00f, 0, 1, cg_dp(2, 0, 0)}, // 48 the same on the deep ring
     // 139264 rows = 725.3 tiles of 192: three rounds of 3/4-size tiles and no leftover launch, against two rounds of 256-row tiles
     // plus a leftover launch that costs ~0.7 of a round
-    {192, 320, 2, 2, 64, 2, 1, 1.35f, 0, 1}, // 49 one wave per SIMD, 96x160 per wave (a[0:239])
+    {192, 320, 2, 2, 64, 2, 1, 1.35f, 0, 1, cg_dp(6, 5, 5)}, // 49 one wave per SIMD, 96x160 per wave (a[0:239])
 };
 constexpr int kNumCgCfgs = sizeof(kCgCfgs) / sizeof(kCgCfgs[0]);
 
@@ -193,16 +196,27 @@ struct CgPlan {
     int tail_cfg;       // rows [m_main, M): tile table index ...
     int tail_splits;    // ... and K split count (> 1: big tile, partials of the tail rows only)
     size_t workspace;   // bytes of fp32 scratch the plan needs (0: none)
+    int tickets;        // > 0: the K-split launch (whole call or tail) finishes inside the kernel with this many ticket counters
 };
 
+// A K-split launch of `cfg` over rows [m_begin, M) can finish inside the kernel (AaConvGemm.tickets): hand-scheduled tiles only
+// (the compiled kernels keep partials + reduce launch), no folded LayerNorm (its rank-1 terms live in the reduce kernel).
+static int cg_ticket_count(const AaConvGemm& d, int cfg, int m_begin, int M) {
+    if (!d.tickets || cfg < 0 || !kCgCfgs[cfg].x || d.ln_stats || (d.debug & 8)) return 0;
+    const CgCfg& c = kCgCfgs[cfg];
+    if (!cgx_ticket_ok(c.bm, c.bn, c.wm, c.wn, c.per_cu)) return 0;
+    const int wgs = ((M - m_begin + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
+    return wgs <= d.tickets_len ? wgs : 0;
+}
+
 static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) {
-    CgPlan p = {cg_choose(d, M), 1, M, -1, 1, 0};
+    CgPlan p = {cg_choose(d, M), 1, M, -1, 1, 0, 0};
     if (p.cfg < 0) return p;
     const CgCfg& c = kCgCfgs[p.cfg];
     const bool probe = (d.debug & 8) != 0;               // phase probe: the workspace holds time stamps, one plain launch
     if (probe) return p;
     p.splits = have_workspace_or_query ? cg_splits(d, M, c) : 1;
-    if (p.splits > 1) { p.workspace = (size_t)p.splits * M * d.n_pad * 4; return p; }
+    if (p.splits > 1) { p.workspace = (size_t)p.splits * M * d.n_pad * 4; p.tickets = cg_ticket_count(d, p.cfg, 0, M); return p; }
     p.splits = 1;
     // Tiles of one or two workgroups per CU run in lock-step rounds of 256 (512); a sparsely filled last round wastes most of
     // the chip (the 139264-row level is 2.125 rounds of 256-row tiles AND of 128-row tiles at two per CU).
@@ -232,6 +246,7 @@ static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) 
         p.tail_cfg = c.slab ? (c.bn == 320 ? 14 : 15) : p.cfg;       // (the slab kernel does not split K: its im2col twin does)
         p.tail_splits = ts;
         p.workspace = (size_t)ts * (M - p.m_main) * d.n_pad * 4;
+        p.tickets = cg_ticket_count(d, p.tail_cfg, p.m_main, M);
         return p;
     }
     const int small[3] = {47, 1, 0};                       // 128x128 (hand-scheduled, then compiled), 128x64
@@ -376,17 +391,20 @@ static int conv_gemm_t(const AaConvGemm& d, void* stream) {
             if (blocks > 4096) blocks = 4096;
             AA_LAUNCH((splitk_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, d, M, m_begin, splits);
         };
+        // the kernels finish a K split themselves iff they see a ticket array: hand it over only where the plan counted on it
+        AaConvGemm dk = d;
+        if (!pl.tickets) dk.tickets = nullptr;
         if (pl.splits > 1) {
-            cg_launch_cfg<T>(pl.cfg, d, 0, M, stream, pl.splits);
-            reduce(0, pl.splits);
+            cg_launch_cfg<T>(pl.cfg, dk, 0, M, stream, pl.splits);
+            if (!pl.tickets) reduce(0, pl.splits);
             return finish("conv_gemm");
         }
-        cg_launch_cfg<T>(pl.cfg, d, 0, pl.m_main, stream);
+        cg_launch_cfg<T>(pl.cfg, dk, 0, pl.m_main, stream);
         if (pl.m_main < M) {
-            AaConvGemm tail = d;
+            AaConvGemm tail = dk;
             tail.tile = -1;
             cg_launch_cfg<T>(pl.tail_cfg, tail, pl.m_main, M, stream, pl.tail_splits);
-            if (pl.tail_splits > 1) reduce(pl.m_main, pl.tail_splits);
+            if (pl.tail_splits > 1 && !pl.tickets) reduce(pl.m_main, pl.tail_splits);
         }
         return finish("conv_gemm");
     }
@@ -543,22 +561,53 @@ int aa_conv_gemm_row_stats_parts(const AaConvGemm* d) {
     if (pl.workspace > (size_t)d->workspace_bytes) pl = cg_plan(*d, M, false);
     const CgCfg& c = kCgCfgs[pl.cfg];
     // only the branch-free epilogue forms of the hand-scheduled tiles emit them, in ONE launch that covers every row
-    if (!c.x || pl.splits > 1 || pl.m_main < M || (d->debug & 8)) return 0;
+    if (!c.x || (pl.splits > 1 && !pl.tickets) || pl.m_main < M || (d->debug & 8)) return 0;      // (a K split that finishes in the kernel runs the same epilogue)
     return (d->n_pad / c.bn) * c.wn;
+}
+
+static bool cg_plan_of(const AaConvGemm* d, aa::CgPlan& pl, int& M) {
+    using namespace aa;
+    if (!d || !cg_dma_ok(*d)) return false;
+    M = (int)((int64_t)d->n_img * d->h_out * d->w_out);
+    pl = cg_plan(*d, M, d->workspace != nullptr);
+    if (pl.cfg < 0) return false;
+    if (pl.workspace > (size_t)d->workspace_bytes) pl = cg_plan(*d, M, false);
+    return true;
+}
+
+int aa_conv_gemm_reduce_launches(const AaConvGemm* d) {
+    aa::CgPlan pl; int M;
+    if (!cg_plan_of(d, pl, M) || pl.tickets) return 0;
+    if (pl.splits > 1) return 1;
+    return (pl.m_main < M && pl.tail_splits > 1) ? 1 : 0;
+}
+
+int aa_conv_gemm_tickets(const AaConvGemm* d) {
+    aa::CgPlan pl; int M;
+    if (!d) return 0;
+    // (asked with a stand-in array: how many counters WOULD the call use)
+    AaConvGemm q = *d;
+    static int32_t probe_array;
+    if (!q.tickets) { q.tickets = &probe_array; q.tickets_len = 0x7fffffff; }
+    if (!cg_plan_of(&q, pl, M)) return 0;
+    return pl.tickets;
 }
 
 int aa_conv_gemm_launch_count(const AaConvGemm* d) {
     using namespace aa;
     if (!d) return 0;
     if (!cg_dma_ok(*d)) return 1;
-    const int M = (int)((int64_t)d->n_img * d->h_out * d->w_out);
-    CgPlan pl = cg_plan(*d, M, d->workspace != nullptr);
-    if (pl.cfg < 0) return 0;
-    if (pl.workspace > (size_t)d->workspace_bytes) pl = cg_plan(*d, M, false);
-    if (pl.splits > 1) return 2;
+    CgPlan pl; int M;
+    if (!cg_plan_of(d, pl, M)) return 0;
     int n = 1;
-    if (pl.m_main < M) n += 1 + (pl.tail_splits > 1 ? 1 : 0);
-    return n;
+    if (pl.splits == 1 && pl.m_main < M) n += 1;
+    return n + aa_conv_gemm_reduce_launches(d);
+}
+
+int aa_conv_gemm_tile_flags(int idx) {
+    if (idx < 0 || idx >= aa::kNumCgCfgs) return -1;
+    const aa::CgCfg& c = aa::kCgCfgs[idx];
+    return (c.slab ? 1 : 0) | (c.x ? 2 : 0) | (c.sched << 2);
 }
 
 int aa_conv_gemm(const AaConvGemm* d, void* stream) {

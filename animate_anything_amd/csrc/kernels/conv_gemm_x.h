@@ -31,6 +31,13 @@ __host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring, i
     return cgd_lds_bytes(bm, bn, bk, ring) + (cgx_ln_ok(bk, wm, wn, per_cu) ? wm * wn * 2048 : 0);
 }
 
+// Tiles whose K-split launches can finish inside the kernel (AaConvGemm.tickets): the second epilogue instance needs registers - one
+// wave per SIMD (512 per lane), or the 128 x 128 tiles (64 accumulation registers).  With 128 literal accumulation registers next to
+// 128 VGPRs hipcc parks values in accumulation registers it believes free (tests/test_abi.py counts v_accvgpr_write: r04 build).
+__host__ __device__ constexpr bool cgx_ticket_ok(int bm, int bn, int wm, int wn, int per_cu) {
+    return (wm * wn * per_cu + 3) / 4 == 1 || (bm / wm / 32) * (bn / wn / 32) <= 4;
+}
+
 // DP3 / DP0 / DP1: LDS-DMA pieces (per wave) of the tile after next issued under sub-step 3 of a K step and under
 // sub-steps 0 / 1 of the following one (the rest under sub-step 2); activations first (they may come from HBM).
 //
@@ -488,7 +495,67 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
                 }
             });
         });
+        if constexpr (!cgx_ticket_ok(BM, BN, WM, WN, PER_CU)) return;
+        else {
+        if (p.tickets == nullptr) return;                        // the host follows up with splitk_reduce_kernel
+        // ---- finish inside the kernel (AaConvGemm.tickets): the LAST of this tile's k_splits workgroups to get here sums the
+        // partials in split order - its own from the accumulation registers (bit-identical to what it stored), the others from
+        // the workspace - and runs the usual epilogue.  Release / acquire as in the classic last-block reduction: fence behind the
+        // partial stores of every wave, barrier, one ticket per workgroup, fence in front of the reads.  The counter goes back
+        // to zero for the next launch (nobody else touches it after the last ticket was drawn).
+        int* last_flag = reinterpret_cast<int*>(dummy);
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            const int ticket = atomicAdd(p.tickets + blockIdx.x, 1);
+            const int last = ticket == k_splits - 1;
+            if (last) p.tickets[blockIdx.x] = 0;
+            *last_flag = last;
+        }
+        __syncthreads();
+        if (*last_flag == 0) return;
+        __threadfence();
+        const int my_split = blockIdx.y;
+        const float* ws0 = reinterpret_cast<const float*>(p.workspace) - (int64_t)m_begin * p.n_pad;
+        const int64_t split_stride = (int64_t)(M - m_begin) * p.n_pad;
+        const BufRsrc r_cb = make_rsrc(p.bias, (p.bias && !p.bias_per_row) ? (unsigned)p.n_out * 2u : 0u);      // (per-row biases: general epilogue)
+        auto get_sum = [&](auto i_, auto j_) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_)::value, j = decltype(j_)::value;
+            const int m = min(m_tile + wm * (BM / WM) + i * 32 + ec, M - 1);               // (rows behind the tensor: any finite value, never stored)
+            const float* src = ws0 + (int64_t)m * p.n_pad + n_wave + j * 32 + 16 * eh;
+            const f32x16 own = acc_get<i * NI + j>(af);
+            f32x16 v;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = 0.0f;
+            for (int sp = 0; sp < k_splits; ++sp) {
+                if (sp == my_split) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] += own[e];
+                } else {
+                    const f32x4* q4 = reinterpret_cast<const f32x4*>(src + sp * split_stride);
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const f32x4 t = q4[qq];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * qq + e] += t[e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {                     // the accumulators of a split started from zero: the column bias joins here
+                Pack8<T> b; b.raw = buf_load16(r_cb, (unsigned)(n_wave + j * 32 + 16 * eh + 8 * qq) * 2u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[8 * qq + e] += (float)b.e[e];
+            }
+            return v;
+        };
+        LnRstd<MI> no_ln;
+        no_ln.on = false;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) no_ln.v[i] = 1.0f;
+        cgd_epilogue_g<T, MI, NI, true>(p, M, get_sum, m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN), p.row_stats ? tile_n * WN + wn : -1, no_ln);
         return;
+        }
     }
     cgd_epilogue_g<T, MI, NI, true>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) { return acc_get<decltype(i_)::value * NI + decltype(j_)::value>(af); },
                               m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN),

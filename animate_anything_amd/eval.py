@@ -77,6 +77,18 @@ def preprocess_image(pimg, height, width):
     return 2.0 * x - 1.0
 
 
+def load_motion_mask(path, width, height):
+    """train.py:750-756: the mask image resized to the pixel size with every non-zero value set to 255 (JPEG ringing around the
+    region counts as "moving"), or all-255 without a mask.  uint8 [height, width]."""
+    if path:
+        np_mask = np.array(Image.open(path).resize((width, height)))
+        if np_mask.ndim == 3:
+            np_mask = np_mask[..., 0]
+        np_mask[np_mask != 0] = 255
+        return np_mask
+    return np.ones([height, width], dtype=np.uint8) * 255
+
+
 def mask_to_latent(np_mask, h, w):
     """T.ToTensor()(np_mask) then T.Resize([h,w], antialias=False) (train.py:761-764) -> [1,1,1,h,w]."""
     m = torch.from_numpy(np_mask.astype(np.float32) / 255.0)[None, None]
@@ -159,14 +171,7 @@ def eval(pipeline, validation_data, out_file, index, forward_t=25, preview=True,
     input_image = input_image.unsqueeze(0).to(dtype).to(device)
     input_image_latents = tensor_to_vae_latent(input_image, vae)
 
-    if "mask" in validation_data and validation_data.mask:
-        mask = Image.open(validation_data.mask).resize((validation_data.width, validation_data.height))
-        np_mask = np.array(mask)
-        if np_mask.ndim == 3:
-            np_mask = np_mask[..., 0]
-        np_mask[np_mask != 0] = 255
-    else:
-        np_mask = np.ones([validation_data.height, validation_data.width], dtype=np.uint8) * 255
+    np_mask = load_motion_mask(validation_data.mask if "mask" in validation_data else None, validation_data.width, validation_data.height)
     Image.fromarray(np_mask).save(os.path.splitext(out_file)[0] + "_mask.jpg")
 
     initial_latents, timesteps = DDPM_forward_timesteps(input_image_latents, forward_t, validation_data.num_frames,

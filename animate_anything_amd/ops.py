@@ -34,6 +34,10 @@ MAX_OPERAND_BYTES = 1 << 31      # the contraction kernel's 32-bit operand offse
 FORCE_TILE = -1       # tests / sweeps: >= 0 puts this tile-table index into AaConvGemm.tile of every conv_gemm call (strict: ineligible = error)
 ATTN_FLAGS = 0        # experiments: AaAttention._pad (bit 0: s_setprio 1 around the matrix clusters of the head_dim-64 kernel)
 K_SPLITS = 0          # tests: explicit K split count for calls that are not autotuned (0 = library decides)
+# K-split launches of the hand-scheduled tiles can finish inside the kernel (AaConvGemm.tickets, ABI 106).  Measured on the step (r04g):
+# not faster than partials + reduce launch (the autotuner moved the 8x8-level shapes to the compiled tile + reduce launch; step 62.5 ms
+# with, 61.9 ms without) - the release / acquire fences around the ticket write back and invalidate the XCD's L2.  Off unless asked for.
+USE_TICKETS = os.environ.get("AA_TICKETS", "0") == "1"
 DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
 class _TileTable:
     """The library's tile table (aa_conv_gemm_tile_info), read on first use: entries (rows, columns, K step, stages)."""
@@ -45,7 +49,7 @@ class _TileTable:
         if self._rows is None:
             lib, rows, info = _lib.get(), [], (C.c_int32 * 7)()
             while lib.aa_conv_gemm_tile_info(len(rows), info) == 0:
-                rows.append(tuple(info))
+                rows.append(tuple(info) + (int(lib.aa_conv_gemm_tile_flags(len(rows))),))
             self._rows = rows
         return self._rows
 
@@ -64,6 +68,10 @@ class _TileTable:
 
     def per_cu(self, i):
         return self._load()[i][6]
+
+    def flags(self, i):
+        """aa_conv_gemm_tile_flags: bit 0 halo-slab kernel, bit 1 hand-scheduled stream, higher bits the DMA schedule."""
+        return self._load()[i][7]
 
 
 TILE_TABLE = _TileTable()
@@ -114,6 +122,34 @@ def _load_default_tile_cache():
                 pass
 
 
+TICKET_COUNTERS = 1 << 16
+_tickets = {}
+
+
+def _ticket_array(t: torch.Tensor):
+    """The zero-initialised counter array of AaConvGemm.tickets for the stream `t`'s calls run on: one per (device, stream) -
+    K-split launches in flight on different streams must not share counters; the kernels hand every counter back as zero.
+    Launches recorded into a hipGraph use a separate array per device (a capture stream is short-lived; the replays of the
+    graphs of one device run one at a time in this package).  Never allocated inside a capture: a call captured before any eager
+    call on that device gets None (partials + reduce launch)."""
+    if not t.is_cuda:
+        if not _lib.host_pointers_ok():
+            return None
+        a = _tickets.get("host")
+        if a is None:
+            a = _tickets["host"] = torch.zeros(TICKET_COUNTERS, dtype=torch.int32)
+        return a
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (str(t.device), "graph" if capturing else torch.cuda.current_stream(t.device).cuda_stream)
+    a = _tickets.get(key)
+    if a is None and not capturing:
+        a = _tickets[key] = torch.zeros(TICKET_COUNTERS, dtype=torch.int32, device=t.device)
+        gkey = (str(t.device), "graph")
+        if gkey not in _tickets:
+            _tickets[gkey] = torch.zeros(TICKET_COUNTERS, dtype=torch.int32, device=t.device)
+    return a
+
+
 def _tile_candidates(d, rows):
     """(tile, k_splits) pairs worth timing: every tile shape that divides the packed width with the library's own split
     decision (0), plus explicit K splits where they turn an under-filled single round of workgroups into (nearly)
@@ -127,7 +163,7 @@ def _tile_candidates(d, rows):
         if not lib.aa_conv_gemm_tile_ok(C.byref(d), i):                 # width, GEGLU pairing, slab-kernel geometry
             continue
         out.append((i, 0))
-        if bk == 32 and _st == 3:                                       # halo-slab kernel: no K split
+        if TILE_TABLE.flags(i) & 1:                                     # halo-slab kernel: no K split
             continue
         if d.geglu or bm < 128:
             continue
@@ -169,7 +205,7 @@ def _autotune(lib, d, stream, key, rows, dev):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ws_keep = (d.workspace, d.workspace_bytes)
 
-        def timed(c, sp, reps):
+        def timed(c, sp, reps, raw=False):
             d.tile, d.k_splits = c, sp
             need = lib.aa_conv_gemm_workspace(C.byref(d))
             ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=dev)
@@ -185,12 +221,23 @@ def _autotune(lib, d, stream, key, rows, dev):
                 e1.record()
                 e1.synchronize()
                 ts.append(e0.elapsed_time(e1))
+            if raw:
+                return ts
             ts.sort()
             return ts[len(ts) // 2] if reps > 5 else ts[1]
 
-        # screening pass over every candidate, then a longer run-off between the three fastest
+        # screening pass over every candidate, then a run-off between the four fastest: three interleaved passes of seven launches
+        # each, median of the 21 (r04: with one 11-launch pass per finalist the choice flipped between runs on close calls - clock /
+        # power drift during a pass favours whoever runs at the right moment - and a flipped 3x3 choice costs 0.1 ms of the step)
         first = sorted((t, c) for c in cands for t in [timed(c[0], c[1], 5)] if t is not None)
-        final = sorted((t, c) for _, c in first[:3] for t in [timed(c[0], c[1], 11)] if t is not None)
+        finalists = [c for _, c in first[:4]]
+        samples = {c: [] for c in finalists}
+        for _ in range(3):
+            for c in finalists:
+                ts = timed(c[0], c[1], 7, raw=True)
+                if ts is not None:
+                    samples[c] += ts
+        final = sorted((sorted(v)[len(v) // 2], c) for c, v in samples.items() if v)
         if final:
             best = final[0][1]
         d.workspace, d.workspace_bytes = ws_keep
@@ -513,6 +560,9 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
         raise ValueError("conv_gemm: acc_scale == 0 is not representable (0 means 1 in the C ABI)")
     d.k_order = pw.k_order
     d.debug = DEBUG_ABLATE
+    tk = _ticket_array(x0) if USE_TICKETS else None
+    if tk is not None:
+        d.tickets, d.tickets_len = _ptr(tk), tk.numel()
     d.tile, d.k_splits = -1, K_SPLITS
     if AUTOTUNE and x0.is_cuda and FORCE_TILE < 0 and K_SPLITS == 0:      # (explicit tile / split requests of tests and sweeps are not re-tuned)
         key = (d.dtype, g.n_img, g.h_in, g.w_in, d.h_virt, d.w_virt, g.h_out, g.w_out, g.stride, pw.kh, pw.kw, c0, c1,

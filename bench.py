@@ -141,7 +141,8 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
     """Re-time the recorded contraction calls of ONE step back to back on the current stream (the stream the kernels run on)
     between two events, and account for them: FLOP and ALGORITHMIC bytes from the descriptors (unique input + weights +
     output (+ residual) of every call, what a perfect kernel moves once), kernel launches from the library's own plan
-    (aa_conv_gemm_launch_count: main launch + split-off last round + split-K reduce), measured HBM bytes from the last committed
+    (aa_conv_gemm_launch_count minus aa_conv_gemm_reduce_launches: main launch + split-off last round; the split-K reduce launches that
+    remain - K splits of the hand-scheduled tiles finish inside the kernel - are reported apart), measured HBM bytes from the last committed
     PMC run of the same command (profiles/r0N_traffic_pmc.json: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes -
     bench.py cannot profile itself)."""
     import ctypes as C
@@ -149,7 +150,10 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
     lib = _lib.get()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     flops = sum(2.0 * d.n_img * d.h_out * d.w_out * d.n_out * d.kh * d.kw * (d.c0 + d.c1) for d, _ in trace)
-    launches = sum(int(lib.aa_conv_gemm_launch_count(C.byref(d))) for d, _ in trace)
+    # ONE definition: contraction-kernel launches and split-K reduce launches are counted apart; `avg_kernel_launch_us`
+    # and the PMC bytes per launch refer to the contraction kernels only
+    reduces = sum(int(lib.aa_conv_gemm_reduce_launches(C.byref(d))) for d, _ in trace)
+    launches = sum(int(lib.aa_conv_gemm_launch_count(C.byref(d))) for d, _ in trace) - reduces
     alg_bytes = 0.0
     for d, _ in trace:
         m = d.n_img * d.h_out * d.w_out
@@ -193,7 +197,7 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
                         f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} {v[3]:>4s} {v[1] / tot * 100:5.1f}%\n")
     ach = flops / (gemm_ms * 1e-3) / 1e12
     traffic, tname, t_launches = None, None, None
-    for tname_ in ("r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):     # newest committed PMC measurement
+    for tname_ in ("r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):     # newest committed PMC measurement
         tpath = os.path.join(ROOT, "profiles", tname_)
         if os.path.exists(tpath):
             rec = json.load(open(tpath))
@@ -206,7 +210,7 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
             "traffic_unit": f"HBM bytes per KERNEL LAUNCH of the contraction kernels, measured (PMC, profiles/{tname}: that run had "
                             f"{t_launches} such launches per step)",
             "kernel": "contraction kernels: aa::conv_gemm_dma_kernel / conv3x3_slab_kernel / conv_gemm_x_kernel (LDS-DMA implicit-GEMM conv / linear), all instances",
-            "kernel_launches_per_step": launches, "aa_conv_gemm_calls_per_step": len(trace),
+            "contraction_launches_per_step": launches, "reduce_launches_per_step": reduces, "aa_conv_gemm_calls_per_step": len(trace),
             "avg_kernel_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
             "flop_per_step_in_kernel": flops, "kernel_ms_per_step": round(gemm_ms, 3),
             "algorithmic_bytes_per_step": round(alg_bytes), "traffic_bytes_per_step": traffic_step,

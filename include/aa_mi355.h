@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AA_VERSION 105
+#define AA_VERSION 106
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
@@ -115,7 +115,14 @@ typedef struct AaConvGemm {
     float* row_stats;       /* producer: [M][row_stats_parts][2] fp32: (sum, sum of squares) of the stored output row over the columns of
                                one wave of the tile - written iff row_stats_parts == aa_conv_gemm_row_stats_parts(d) > 0 */
     int32_t row_stats_parts;
-    int32_t _pad105;
+    /* version 106: K-split calls that finish INSIDE the kernel.  `tickets` = a caller-owned, zero-initialised int32 array of at
+     * least aa_conv_gemm_tickets(d) entries that holds zeros between calls (the kernels leave it zeroed; one array per stream -
+     * calls in flight on different streams must not share one).  With it a K-split launch of a hand-scheduled tile needs no reduce
+     * launch: every workgroup writes its fp32 partial tile, takes a ticket of its output tile, and the LAST one to arrive sums the
+     * partials in split order (a fixed order whichever workgroup it is: results are bit-reproducible, no floating-point atomics)
+     * and runs the usual epilogue.  NULL: partials + splitk reduce launch as before. */
+    int32_t tickets_len;
+    int32_t* tickets;
 } AaConvGemm;
 
 /* Bytes of fp32 scratch with which aa_conv_gemm would split the K loop of this call over several workgroups
@@ -125,6 +132,12 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream);
 /* Number of kernel launches aa_conv_gemm makes for this descriptor (version 103): 1, plus a launch for a split-off last
  * round of tiles, plus split-K reduce launches - what a profiler counts per call (bench.py `roofline.kernel_launches_per_step`). */
 int aa_conv_gemm_launch_count(const AaConvGemm* d);
+/* Ticket counters this call would use when `tickets` is given (version 106): the workgroups of its K-split launch, 0 when the call
+ * is not split along K or its tile keeps the reduce launch (compiled tiles, a folded LayerNorm). */
+int aa_conv_gemm_tickets(const AaConvGemm* d);
+/* How many of aa_conv_gemm_launch_count's launches are split-K reduce launches (version 106; bench.py reports the contraction
+ * launches and the reduce launches of a step separately). */
+int aa_conv_gemm_reduce_launches(const AaConvGemm* d);
 /* Partial row statistics per output row that aa_conv_gemm would write for this descriptor when `row_stats` is set (version 105):
  * 0 when the way it carries the call out cannot emit them (compiled tiles, K splits, a split-off last round) - the caller then runs
  * the LayerNorm it wanted to fold as a kernel. */
@@ -137,6 +150,11 @@ int aa_ln_finalize(const float* stats, int32_t parts, float* coef, int64_t rows,
 /* Tile table of the LDS-DMA contraction kernel (what `AaConvGemm.tile` indexes): fills info[0..6] = rows, columns, wave
  * rows, wave columns, K step, ring stages, workgroups per CU of entry `idx`; returns 0, or -1 past the end of the table. */
 int aa_conv_gemm_tile_info(int idx, int32_t info[7]);
+
+/* Kernel family / schedule of entry `idx` (version 106): bit 0 halo-slab 3x3 kernel (no K split), bit 1 hand-scheduled stream
+ * (conv_gemm_x.h), bit 2 staggered / bit 3 spread DMA issue of the compiled kernel, bits 8.. the hand-scheduled kernel's DMA
+ * schedule (DP3 | DP0 << 4 | DP1 << 8); -1 past the end of the table.  Part of what identifies a saved tile choice. */
+int aa_conv_gemm_tile_flags(int idx);
 
 /* 1 when entry `idx` of the tile table can carry out this call (packed width divisible by the tile, GEGLU pairing, the
  * geometry preconditions of the halo-slab 3x3 kernel), else 0: what an autotuner should restrict itself to. */

@@ -169,6 +169,9 @@ inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 using std::min;
 using std::max;
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+// the workgroups of a launch run on concurrent host threads: tickets (AaConvGemm.tickets) need the real thing
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 inline float wave_shfl_xor(float v, int mask) {
     float out = 0.0f;

@@ -125,5 +125,5 @@ def test_x_kernels_keep_hipcc_out_of_the_accumulators(tmp_path):
         assert writes % (16 * literal_blocks) == 0 and 2 <= writes // (16 * literal_blocks) <= 8, (name, writes)      #  from a folded LayerNorm two forms per site)
         # read-out sites (split-K partials, the general epilogue, its branch-free forms) read every block exactly once each
         reads = len(re.findall(r"v_accvgpr_read", body))
-        assert 2 * 16 * literal_blocks <= reads <= 16 * 16 * literal_blocks, (name, reads)     # (r04: + LayerNorm-fold / row-statistics forms; hipcc may clone part of a form)
+        assert 2 * 16 * literal_blocks <= reads <= 32 * 16 * literal_blocks, (name, reads)     # (r04: + LayerNorm-fold / row-statistics forms, a second epilogue instance behind an in-kernel K-split finish; hipcc may clone part of a form)
         assert "scratch_" not in body, name

@@ -452,11 +452,18 @@ def test_layernorm_fold_through_split_k_and_producers_that_cannot_emit(backend):
     ops.K_SPLITS, ops.FORCE_TILE = 3, 36
     try:
         z = ops.conv_gemm(y, ops.pack_weight(w1, b1, ln=(gamma, beta, 1e-5)), ops.linear_geom(M), ln_stats=st)
+        ops.USE_TICKETS = False
         _, none1 = ops.conv_gemm(y, ops.pack_weight(w1, b1), ops.linear_geom(M), row_stats=True)
+        ops.USE_TICKETS = True                    # (r04) a K split that finishes inside the kernel runs the usual epilogue: statistics included
+        v, some = ops.conv_gemm(y, ops.pack_weight(w1, b1), ops.linear_geom(M), row_stats=True)
     finally:
-        ops.K_SPLITS, ops.FORCE_TILE = 0, -1
+        ops.K_SPLITS, ops.FORCE_TILE, ops.USE_TICKETS = 0, -1, True
     close(z, F.layer_norm(yf, (C,), gamma.float(), beta.float(), 1e-5) @ w1.float().t() + b1.float())
     assert none1 is None
+    assert some is not None and some.rows == M
+    tot = some.data.float().sum(dim=1).cpu()
+    close(tot[:, 0], v.float().sum(dim=1), tol=2e-3)
+    close(tot[:, 1], (v.float() ** 2).sum(dim=1), tol=2e-3)
     ops.FORCE_TILE = 1
     try:
         _, none2 = ops.conv_gemm(y, ops.pack_weight(w1, b1), ops.linear_geom(M), row_stats=True)
@@ -539,6 +546,68 @@ def test_explicit_k_splits(backend, cfg, splits):
         ops.FORCE_TILE = -1
     ref = nhwc(F.silu(F.conv2d(x.float(), wt.float(), b.float(), padding=1))).half().float() + res.float()
     close(y, ref)
+
+
+@pytest.mark.parametrize("cfg,splits,form", [(36, 3, "residual"), (39, 2, "rowvec"), (46, 4, "silu"), (47, 5, "plain"), (48, 3, "rowbias"),
+                                              (49, 3, "rowvec_residual"), (41, 4, "residual"), (42, 2, "plain"), (37, 3, "mapped")])
+def test_k_split_finishes_inside_the_kernel(backend, cfg, splits, form):
+    """AaConvGemm.tickets (ABI 106): the last workgroup of a tile to arrive sums the partials in split order and runs the epilogue -
+    no reduce launch.  Every epilogue form a split call can carry, against fp32 torch, against the reduce-launch form of the same
+    call, twice in a row (the counters come back as zeros; results are bit-identical run to run)."""
+    import ctypes as C
+    from animate_anything_amd import _lib
+    n, h, w, cin = 2, 9, 11, 128
+    N = 320 if ops.TILE_TABLE[cfg][1] == 320 else 256
+    x, wt, b = rnd(n, cin, h, w, seed=301), rnd(N, cin, 3, 3, scale=0.05, seed=302), rnd(N, seed=303)
+    g = ops.conv3x3_geom(n, h, w)
+    res, rv, rb = rnd(g.rows, N, seed=304), rnd(n, N, seed=305), rnd(g.rows, seed=306)
+    kw, ref = {}, F.conv2d(x.float(), wt.float(), b.float(), padding=1)
+    if form == "residual":
+        kw, ref = dict(residual=res, out_scale=0.5), (nhwc(ref) + res.float()) * 0.5
+    elif form == "rowvec":
+        kw, ref = dict(rowvec=rv, rowvec_div=h * w), nhwc(ref) + rv.float().repeat_interleave(h * w, 0)
+    elif form == "silu":
+        kw, ref = dict(act=AA_ACT_SILU, residual=res), nhwc(F.silu(ref)) + res.float()
+    elif form == "rowbias":
+        kw, ref = dict(bias=rb, bias_per_row=True), nhwc(F.conv2d(x.float(), wt.float(), None, padding=1)) + rb.float()[:, None]
+    elif form == "rowvec_residual":
+        kw, ref = dict(rowvec=rv, rowvec_div=h * w, residual=res, acc_scale=0.75), (nhwc(ref) + rv.float().repeat_interleave(h * w, 0)) * 0.75 + res.float()
+    elif form == "mapped":
+        ref = nhwc(ref)
+    else:
+        ref = nhwc(ref)
+    pw = ops.pack_weight(wt, b)
+    lib = _lib.get()
+
+    def run(tickets):
+        out = None
+        if form == "mapped":                          # rows scattered over a 2x2-finer output grid (the Upsample2D parity classes)
+            out = torch.zeros(g.rows * 4, N, dtype=DT, device=DEV)
+            kw["out_map"] = (2, 2, 1, 0)
+        ops.FORCE_TILE, ops.K_SPLITS, ops.USE_TICKETS, ops.TRACE = cfg, splits, tickets, []
+        try:
+            y = ops.conv_gemm(nhwc(x), pw, g, out=out, **kw)
+            d = ops.TRACE[0][0]
+            counts = (lib.aa_conv_gemm_launch_count(C.byref(d)), lib.aa_conv_gemm_reduce_launches(C.byref(d)), lib.aa_conv_gemm_tickets(C.byref(d)))
+        finally:
+            ops.FORCE_TILE, ops.K_SPLITS, ops.USE_TICKETS, ops.TRACE = -1, 0, True, None
+        if form == "mapped":
+            y = y.reshape(n, h, 2, w, 2, N)[:, :, 1, :, 0].reshape(-1, N)
+        return y, counts
+
+    y1, c1 = run(True)
+    assert c1[0] == 1 and c1[1] == 0 and c1[2] > 0, c1          # one launch, no reduce launch, one counter per workgroup of grid.x
+    tk = ops._ticket_array(nhwc(x))
+    if DEV == "cuda":
+        torch.cuda.synchronize()
+    assert int(tk.abs().sum().item()) == 0                       # every counter handed back as zero
+    y2, _ = run(True)
+    y0, c0 = run(False)
+    assert c0[0] == 2 and c0[1] == 1, c0                         # the same call with partials + reduce launch
+    close(y1, ref)
+    close(y0, ref)
+    assert torch.equal(y1, y2)
+    close(y1, y0.float(), tol=2e-3)
 
 
 @pytest.mark.parametrize("cfg", [23, 25, 3, 36, 38, 40, 41, 43, 44, 45, 46, 47, 48])
