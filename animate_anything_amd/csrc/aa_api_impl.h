@@ -633,6 +633,8 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream) {
         if (!d->ln_cols || d->bias || d->rowvec || d->residual || d->act != AA_ACT_NONE || d->bias_per_row || d->c1 ||
             d->kh * d->kw != 1 || d->out_scale != 1.0f || (d->acc_scale != 0.0f && d->acc_scale != 1.0f) || !cg_dma_ok(*d) || cgd_out_mapped(*d))
             return fail(AA_E_SHAPE, "conv_gemm: the LayerNorm fold (ln_stats) is a plain or GEGLU linear call: ln_cols, no bias / row vector / residual / activation / scales");
+        if (d->ln_parts < 0 || d->ln_parts > 64 || (d->ln_parts > 0 && !(d->ln_eps > 0.0f)))
+            return fail(AA_E_SHAPE, "conv_gemm: ln_parts=%d (0: finalised coefficients, 1..64: raw partial sums + ln_eps > 0)", d->ln_parts);
     }
     if (d->row_stats && d->row_stats_parts != aa_conv_gemm_row_stats_parts(d))
         return fail(AA_E_SHAPE, "conv_gemm: row_stats_parts=%d, this call emits %d partial statistics per row (aa_conv_gemm_row_stats_parts)", d->row_stats_parts, aa_conv_gemm_row_stats_parts(d));

@@ -59,6 +59,35 @@ struct LnRow { float a, nm, nmean, sd; };
 // caller's array parks it in scratch)
 template <int MI> struct LnRstd { float v[MI]; bool on; };
 __device__ __forceinline__ LnRow cgd_ln_row(const AaConvGemm& p, const int m) {
+    if (p.ln_parts > 0) {
+        // ln_stats = the PRODUCER's partial (sum, sum of squares) pairs, [M][ln_parts][2]: finalised here, in the arithmetic and the
+        // order of ln_finalize_kernel (norm.h) - the 99 finalize launches of a step (4.6 us each, r04g) disappear
+        const float* st = p.ln_stats + (int64_t)m * (p.ln_parts * 2);
+        float s = 0.0f, q = 0.0f;
+        if (p.ln_parts == 2) {                    // a producer tile that spans the row (320 channels): ONE 16-byte load per row, as with coefficients
+            const f32x4 v = *reinterpret_cast<const f32x4*>(st);
+            s = v[0] + v[2]; q = v[1] + v[3];
+        } else if (p.ln_parts == 10) {            // five 128-column (256-column) tiles of two waves: 640 (1280) channels - five independent loads
+            f32x4 v[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) v[t] = *reinterpret_cast<const f32x4*>(st + 4 * t);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { s += v[t][0]; q += v[t][1]; s += v[t][2]; q += v[t][3]; }
+        } else {
+            // (correct for any count, but a chain of dependent loads: measured +12 ... +23 % on the consuming kernels at 10 parts,
+            //  r04h - callers with other part counts keep the aa_ln_finalize launch)
+            for (int t = 0; t < p.ln_parts; ++t) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(st + 2 * t);
+                s += v[0]; q += v[1];
+            }
+        }
+        const float inv_c = 1.0f / (float)p.c0;
+        const float mean = s * inv_c;
+        const float var = fmaxf(q * inv_c - mean * mean, 0.0f);
+        const float sd = sqrtf(var + p.ln_eps);
+        const float rstd = 1.0f / sd;
+        return LnRow{rstd, -mean * rstd, -mean, sd};
+    }
     const f32x4 c = *reinterpret_cast<const f32x4*>(p.ln_stats + (int64_t)m * 4);
     return LnRow{c[2], c[0] * c[2], c[0], c[1]};
 }

@@ -33,6 +33,12 @@ GN_PLANS = None            # a list: groupnorm() appends (groups per workgroup, 
 MAX_OPERAND_BYTES = 1 << 31      # the contraction kernel's 32-bit operand offsets
 FORCE_TILE = -1       # tests / sweeps: >= 0 puts this tile-table index into AaConvGemm.tile of every conv_gemm call (strict: ineligible = error)
 ATTN_FLAGS = 0        # experiments: AaAttention._pad (bit 0: s_setprio 1 around the matrix clusters of the head_dim-64 kernel)
+# A folded LayerNorm's row statistics reach the consumer as aa_ln_finalize's per-row coefficients (one 4.7 us launch per consumer, 99 per
+# step) or raw (ABI 106 `ln_parts`: the consumer finalises 2 / 10 partial sums per row itself with independent loads).  Measured (r04h/i):
+# the raw form removes 80 launches (-0.37 ms) and costs the K = 320 ... 1280 consumers 4-7 % (+0.7 ms: square root, reciprocal and the
+# sums sit in every tile's prologue) - the launch stays the default.
+LN_FINALIZE_LAUNCH = os.environ.get("AA_LN_RAW", "0") != "1"
+LN_RAW_ANY_PARTS = False     # tests: let the consumer finalise any number of partial sums per row (a chain of dependent loads: +12-23 %)
 K_SPLITS = 0          # tests: explicit K split count for calls that are not autotuned (0 = library decides)
 # K-split launches of the hand-scheduled tiles can finish inside the kernel (AaConvGemm.tickets, ABI 106).  Measured on the step (r04g):
 # not faster than partials + reduce launch (the autotuner moved the 8x8-level shapes to the compiled tile + reduce launch; step 62.5 ms
@@ -104,6 +110,10 @@ def load_tile_cache(path):
         _tile_cache[tuple(k)] = tuple(v)
     return True
 
+
+if os.environ.get("AA_DUMP_TILE_CACHE"):                  # debugging aid: what did this process's autotuner choose
+    import atexit
+    atexit.register(lambda: save_tile_cache(os.environ["AA_DUMP_TILE_CACHE"]))
 
 DEFAULT_TILE_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_cache_gfx950.json")
 _default_cache_tried = False
@@ -553,7 +563,12 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     if ln_stats is not None:
         if pw.ln_cols is None or ln_stats.rows != g.rows:
             raise RuntimeError("conv_gemm: ln_stats needs weights packed with a folded LayerNorm and statistics of every row of x0")
-        d.ln_stats, d.ln_cols = _ptr(ln_stats.coef(c0, pw.ln_eps)), _ptr(pw.ln_cols)
+        if LN_FINALIZE_LAUNCH or (ln_stats.parts not in (2, 10) and not LN_RAW_ANY_PARTS):      # aa_ln_finalize in between (r04h: finalising the pieces of a row one dependent load
+                                                                                      # after the other costs the consumer 12-23 %: unrolled forms for 2 / 10 parts only)
+            d.ln_stats, d.ln_cols = _ptr(ln_stats.coef(c0, pw.ln_eps)), _ptr(pw.ln_cols)
+        else:                                             # the kernel finalises the producer's partial sums itself
+            d.ln_stats, d.ln_cols = _ptr(ln_stats.data), _ptr(pw.ln_cols)
+            d.ln_parts, d.ln_eps = ln_stats.parts, float(pw.ln_eps)
     elif pw.ln_cols is not None:
         raise RuntimeError("conv_gemm: these weights carry a folded LayerNorm: pass the row statistics of x0 (ln_stats)")
     if acc_scale == 0.0:

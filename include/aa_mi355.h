@@ -108,10 +108,12 @@ typedef struct AaConvGemm {
      * norm2 -> to_q, norm3 -> GEGLU.proj; the LayerNorm kernel and the normalised tensor disappear).  With W' = W diag(gamma):
      *   LN(x) W^T + b  =  rstd[m] * (x W'^T)[m, n]  -  rstd[m] * mean[m] * colsum(W')[n]  +  (b + beta W^T)[n]
      * The row statistics come from the epilogue of the contraction that PRODUCED x (row_stats). */
-    const float* ln_stats;  /* consumer: [M][4] fp32 per row of the A operand: (-mean, sqrt(var + eps), rstd, 0) - aa_ln_finalize's output; NULL = no fold */
+    const float* ln_stats;  /* consumer, per row of the A operand; NULL = no fold.  ln_parts == 0: [M][4] fp32 (-mean, sqrt(var + eps), rstd, 0) -
+                               aa_ln_finalize's output.  ln_parts > 0 (version 106): [M][ln_parts][2] fp32, the producing call's `row_stats`
+                               as it left them - the kernel finalises them itself (biased variance over c0 channels, `ln_eps`), no launch in between */
     const float* ln_cols;   /* consumer: [2][n_pad] fp32: colsum(W')[n], then (b + beta W^T)[n]; `bias` must be NULL */
-    int32_t ln_parts;       /* reserved: 0 */
-    float ln_eps;           /* reserved */
+    int32_t ln_parts;
+    float ln_eps;           /* with ln_parts > 0: the LayerNorm's epsilon (> 0) */
     float* row_stats;       /* producer: [M][row_stats_parts][2] fp32: (sum, sum of squares) of the stored output row over the columns of
                                one wave of the tile - written iff row_stats_parts == aa_conv_gemm_row_stats_parts(d) > 0 */
     int32_t row_stats_parts;

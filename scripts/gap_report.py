@@ -19,3 +19,18 @@ for a, b in zip(idx[-4:-1], idx[-3:]):
     worst = sorted(zip(gaps, [r['Kernel_Name'][:50] for r in seg], [r['Kernel_Name'][:50] for r in seg[1:]]), reverse=True)[:5]
     for g, x, y in worst:
         print(f"      {g/1e3:7.1f} us  {x} -> {y}")
+
+# per-family totals of the last replayed step
+import re
+seg = rows[idx[-2] + 1:idx[-1] + 1]
+fam = collections.defaultdict(lambda: [0, 0])
+for r in seg:
+    n = r["Kernel_Name"]
+    m = re.search(r"aa::(\w+)", n) or re.search(r"_ZN2aa\d+([a-z0-9_]+?)(?:I|E)", n)
+    k = m.group(1) if m else n[:40]
+    fam[k][0] += 1
+    fam[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+print("last replayed step by kernel family (launches, ms):")
+for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+    print(f"  {k:32s} {v[0]:5d} {v[1] / 1e6:8.3f}")
+print(f"  {'total':32s} {sum(v[0] for v in fam.values()):5d} {sum(v[1] for v in fam.values()) / 1e6:8.3f}")

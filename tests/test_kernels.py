@@ -407,7 +407,8 @@ def test_upsample2x_parity_convs_split_k(backend):
 
 
 @pytest.mark.parametrize("M,C,ptile,ctile,geglu", [(300, 320, 49, 39, False), (300, 320, 39, 36, True), (520, 256, 36, 38, True), (300, 256, 38, 1, False),
-                                                 (200, 640, 49, 49, False), (300, 128, 47, 0, False), (300, 256, 46, 3, True)])
+                                                 (200, 640, 49, 49, False), (300, 128, 47, 0, False), (300, 256, 46, 3, True),
+                                                 (300, 640, 47, 36, True), (200, 1280, 46, 39, False)])     # ten partial sums per row: the unrolled form of the 640 / 1280-channel levels
 def test_layernorm_folded_into_the_consuming_contraction(backend, M, C, ptile, ctile, geglu):
     """diffusers BasicTransformerBlock, norm -> projection (oracle/layers.py:219-224) without a LayerNorm kernel: the producing
     contraction (to_out + residual, hand-scheduled tile `ptile`) leaves partial (sum, sum of squares) per row of what it stores
@@ -432,11 +433,16 @@ def test_layernorm_folded_into_the_consuming_contraction(backend, M, C, ptile, c
     assert pw.bias is None and pw.ln_cols.shape == (2, pw.n_pad)
     ops.FORCE_TILE = ctile
     try:
-        z = ops.conv_gemm(y, pw, ops.linear_geom(M), ln_stats=st)
+        keep = ops.LN_FINALIZE_LAUNCH
+        ops.LN_RAW_ANY_PARTS, ops.LN_FINALIZE_LAUNCH = True, False
+        z = ops.conv_gemm(y, pw, ops.linear_geom(M), ln_stats=st)              # the consumer finalises the partial sums itself (ABI 106: ln_parts)
+        ops.LN_FINALIZE_LAUNCH = True
+        z4 = ops.conv_gemm(y, pw, ops.linear_geom(M), ln_stats=st)             # ... or takes aa_ln_finalize's coefficients: the same arithmetic
     finally:
-        ops.FORCE_TILE = -1
+        ops.FORCE_TILE, ops.LN_FINALIZE_LAUNCH, ops.LN_RAW_ANY_PARTS = -1, keep, False
     h = F.layer_norm(yf, (C,), gamma.float(), beta.float(), 1e-5) @ w1.float().t() + b1.float()
     close(z, h[:, :N] * F.gelu(h[:, N:]) if geglu else h)
+    close(z4, z.float(), tol=1e-3)
     with pytest.raises(RuntimeError):
         ops.conv_gemm(y, pw, ops.linear_geom(M))                      # folded weights without statistics
 

@@ -102,3 +102,29 @@ def test_pipeline_save_pretrained_roundtrip(tmp_path):
     assert again.scheduler.config.beta_end == 0.013 and again.vae_scale_factor == pipe.vae_scale_factor
     for a, b in ((pipe.unet, again.unet), (pipe.vae, again.vae)):
         assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))
+
+
+def test_checkpoint_lookup_rejects_path_variants_and_unpickles_tensors_only(tmp_path):
+    """a caller-supplied `variant` is spliced into the file name - tags only; .bin checkpoints load with
+    weights_only=True (a pickled object that is not a tensor container is refused)."""
+    import pickle
+    import pytest
+    import torch
+    from animate_anything_amd._ckpt import load_state
+    torch.save({"w": torch.ones(2, 3)}, tmp_path / "diffusion_pytorch_model.fp16.bin")
+    sd = load_state(str(tmp_path), "diffusion_pytorch_model", variant="fp16")
+    assert sd["w"].shape == (2, 3)
+    for bad in ("../x", "a/b", "fp16.bin\x00"):
+        with pytest.raises(ValueError):
+            load_state(str(tmp_path), "diffusion_pytorch_model", variant=bad)
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("code ran",))
+    (tmp_path / "evil").mkdir()
+    with open(tmp_path / "evil" / "m.bin", "wb") as f:
+        pickle.dump({"w": Evil()}, f)
+    with pytest.raises(Exception):
+        load_state(str(tmp_path / "evil"), "m")
+    with pytest.raises(FileNotFoundError):
+        load_state(str(tmp_path), "nothing_here")
