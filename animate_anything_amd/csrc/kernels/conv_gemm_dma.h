@@ -152,19 +152,13 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
 #pragma unroll
         for (int i = 0; i < MI; ++i) ln_a[i] = ln_rstd.on ? ln_rstd.v[i] : cgd_ln_row(p, min(m_wave + i * 32 + ec, M - 1)).a;
     }
-    // row statistics of the STORED values (sum, sum of squares over this wave's columns) on the idle matrix pipe: with the two
-    // 16-byte output packs of a block as the B operand, a ones fragment as A gives the row sums in every accumulator row, the
-    // pack itself as A the Gram matrix whose diagonal is the sum of squares (products of 16-bit values are exact in fp32)
-    u32x4 ones_frag;
-    if constexpr (STATS) { Pack8<T> o1; for (int e = 0; e < 8; ++e) o1.e[e] = (T)1.0f; ones_frag = o1.raw; }
+    // row statistics of the STORED values (sum, sum of squares over this wave's columns): two scalars per lane, fed by packed dot
+    // products on the 16-bit output pairs (exact products, fp32 sums); the two half-waves hold the two 16-column halves of a row
+    // and are joined once per block row.  (Not matrix-core products: see dev.h dot2_f32.)
     static_for<MI>([&](auto i_) __attribute__((always_inline)) {
         constexpr int i = decltype(i_)::value;
         const unsigned row = (unsigned)(i * 32 + ec);
-        f32x16 st_sum, st_sq;
-        if constexpr (STATS) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { st_sum[e] = 0.0f; st_sq[e] = 0.0f; }
-        }
+        float st_sum = 0.0f, st_sq = 0.0f;
         const unsigned o_row = !mapped ? row * (unsigned)p.ldo * 2u
                                        : ((int)row < rows_ok ? (unsigned)(cgd_out_row(p, m_wave + (int)row) * p.ldo) * 2u : OOB);
         if constexpr (i + 1 < MI) prefetch(IntTag<i + 1>());
@@ -238,23 +232,21 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
                 if constexpr ((AA_X_ABLATE & 16) != 0) { if (o.raw[0] == 0x12345678u) buf_store16(r_out, o_row + coff[h][q], o.raw); }   // (ablation build: no stores)
                 else buf_store16(r_out, o_row + coff[h][q], o.raw);
                 if constexpr (STATS) {
-                    st_sum = mfma_32x32x16(T(), ones_frag, o.raw, st_sum);
-                    st_sq = mfma_32x32x16(T(), o.raw, o.raw, st_sq);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        st_sum = dot2_f32(T(), o.raw[w], ones_pair(T()), st_sum);
+                        st_sq = dot2_f32(T(), o.raw[w], o.raw[w], st_sq);
+                    }
                 }
             }
         });
         if constexpr (STATS) {
-            // row m = lane & 31: its sum sits in every accumulator row; the diagonal element (m, m) of the Gram matrix in register
-            // (m & 3) + 4 * (m >> 3) of the half-wave (m >> 2) & 1
-            const int idx = (ec & 3) + 4 * (ec >> 3);
-            float sq = st_sq[0];
-#pragma unroll
-            for (int e = 1; e < 16; ++e) sq = idx == e ? st_sq[e] : sq;
+            const float row_sum = wave_sum_halves(st_sum), row_sq = wave_sum_halves(st_sq);      // the other 16 columns of every block
             const int m = m_wave + (int)row;
-            if (eh == ((ec >> 2) & 1) && m < M) {
+            if (eh == 0 && m < M) {
                 float* dst = p.row_stats + ((int64_t)m * p.row_stats_parts + part) * 2;
-                dst[0] = st_sum[0];
-                dst[1] = sq;
+                dst[0] = row_sum;
+                dst[1] = row_sq;
             }
         }
     });

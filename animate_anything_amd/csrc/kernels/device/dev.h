@@ -207,6 +207,23 @@ __device__ __forceinline__ f32x16 acc_get(AccFile& af) {
         return af.v[B - 16];
     }
 }
+// c += a.x * b.x + a.y * b.y on one packed pair of 16-bit values (v_dot2c_f32_f16 / v_dot2c_f32_bf16): products of 16-bit values
+// are exact in fp32.  The row statistics of a contraction's epilogue are built from these (two scalars per lane).  Round 4 first
+// used matrix-core products for them: inside the hand-scheduled kernels the result of the MFMA builtin landed in accumulation
+// registers hipcc believed free - the literal accumulator blocks that had not been read out yet - and for some (tile, epilogue form)
+// pairs the output was wrong by a few per cent of its range (tile 47 without a residual; found by tile fuzzing,
+// scripts/debug/fuzz_tiles_fullsize.py); pinning those accumulators to VGPRs made hipcc spill elsewhere into the same registers.
+__device__ __forceinline__ float dot2_f32(f16_t, unsigned a, unsigned b, float c) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), c, false);
+}
+__device__ __forceinline__ float dot2_f32(bf16_t, unsigned a, unsigned b, float c) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, a), __builtin_bit_cast(b2, b), c, false);
+}
+__device__ __forceinline__ unsigned ones_pair(f16_t) { return 0x3C003C00u; }
+__device__ __forceinline__ unsigned ones_pair(bf16_t) { return 0x3F803F80u; }
+
 // hand-issued 16-byte LDS read from (address ^ X): the XOR sits inside the statement (hipcc would otherwise keep one
 // precomputed address register per sub-step and fragment)
 template <int X>

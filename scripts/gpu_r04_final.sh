@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4 closing run: tile cache for the three workloads (fresh autotune), the whole GPU suite on those choices, smoke, bench lines,
 # rocprof stats (eager) + kernel trace of replayed steps, PMC traffic
-OUT=gpurun_out/r04z
+OUT=gpurun_out/r04zz
 mkdir -p $OUT
 export TMPDIR=/tmp
 TC=$OUT/tile_cache.json
@@ -11,6 +11,9 @@ timeout 1500 python bench.py --workload rgba --steps 3 --warmup 2 --no-cpu-basel
 cp $TC animate_anything_amd/tile_cache_gfx950.json
 timeout 2400 python -m pytest tests -m gpu -x -q -n 3 > $OUT/gpu_tests.log 2>&1; echo "gpu tests rc=$?" >> $OUT/summary.log
 tail -3 $OUT/gpu_tests.log
+timeout 600 python scripts/debug/fuzz_tiles_fullsize.py 80 6 11 > $OUT/fuzz.log 2>&1; echo "tile fuzz rc=$? $(grep -c ' ok' $OUT/fuzz.log) ok $(grep -c FAIL $OUT/fuzz.log) fail" >> $OUT/summary.log
+AA_TICKETS=1 timeout 600 python scripts/debug/fuzz_tiles_fullsize.py 60 4 12 > $OUT/fuzz_tickets.log 2>&1; echo "tile fuzz (tickets) rc=$? $(grep -c ' ok' $OUT/fuzz_tickets.log) ok $(grep -c FAIL $OUT/fuzz_tickets.log) fail" >> $OUT/summary.log
+AA_LN_RAW=1 timeout 600 python scripts/debug/fuzz_tiles_fullsize.py 40 2 13 > $OUT/fuzz_lnraw.log 2>&1; echo "tile fuzz (raw LN statistics) rc=$? $(grep -c ' ok' $OUT/fuzz_lnraw.log) ok $(grep -c FAIL $OUT/fuzz_lnraw.log) fail" >> $OUT/summary.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.log
 tail -1 $OUT/smoke.log
 timeout 900 python bench.py --gemm-breakdown $OUT/gemm_breakdown.txt > $OUT/bench.json 2>$OUT/bench.err; echo "bench rc=$?" >> $OUT/summary.log
@@ -28,11 +31,11 @@ timeout 900 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/gprof -o 
 cd $ROOT
 python scripts/gap_report.py $OUT/gprof > $OUT/graph_step_kernels.txt 2>&1
 find $OUT/gprof -name "*kernel_trace.csv" -delete
-bash scripts/pmc_traffic.sh r04z/traffic > $OUT/traffic.log 2>&1
+bash scripts/pmc_traffic.sh r04zz/traffic > $OUT/traffic.log 2>&1
 cat $OUT/summary.log
 cat $OUT/bench.json | cut -c1-1800
 cat $OUT/bench_svd.json | cut -c1-500
 cat $OUT/bench_rgba.json | cut -c1-500
 cat $OUT/bench_bf16.json | cut -c1-300
 head -22 $OUT/kernel_stats.csv | cut -c1-160
-cat gpurun_out/r04z/traffic/traffic.json | head -60
+cat gpurun_out/r04zz/traffic/traffic.json | head -60

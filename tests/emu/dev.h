@@ -224,6 +224,17 @@ inline f32x16 emu_mfma_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
 }
 inline f32x16 mfma_32x32x16(f16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<f16_t>(a, b, c); }
 inline f32x16 mfma_32x32x16(bf16_t, u32x4 a, u32x4 b, f32x16 c) { return emu_mfma_32x32x16<bf16_t>(a, b, c); }
+// (device/dev.h: v_dot2c_f32_f16 / v_dot2c_f32_bf16 on one packed pair)
+template <typename T>
+inline float emu_dot2(unsigned a, unsigned b, float c) {
+    T x[2], y[2];
+    std::memcpy(x, &a, 4); std::memcpy(y, &b, 4);
+    return c + (float)x[0] * (float)y[0] + (float)x[1] * (float)y[1];
+}
+inline float dot2_f32(f16_t, unsigned a, unsigned b, float c) { return emu_dot2<f16_t>(a, b, c); }
+inline float dot2_f32(bf16_t, unsigned a, unsigned b, float c) { return emu_dot2<bf16_t>(a, b, c); }
+inline unsigned ones_pair(f16_t) { return 0x3C003C00u; }
+inline unsigned ones_pair(bf16_t) { return 0x3F803F80u; }
 
 inline long long clock_now() { static thread_local long long t = 0; return t += 64; }
 inline long long wall_now() { return clock_now(); }

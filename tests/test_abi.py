@@ -127,3 +127,18 @@ def test_x_kernels_keep_hipcc_out_of_the_accumulators(tmp_path):
         reads = len(re.findall(r"v_accvgpr_read", body))
         assert 2 * 16 * literal_blocks <= reads <= 32 * 16 * literal_blocks, (name, reads)     # (r04: + LayerNorm-fold / row-statistics forms, a second epilogue instance behind an in-kernel K-split finish; hipcc may clone part of a form)
         assert "scratch_" not in body, name
+        # a matrix-core product the COMPILER places must not land in accumulation registers: hipcc does not know the literal blocks are
+        # live there (r04: the row-statistics epilogue used the MFMA builtin, its results reused literal blocks and some (tile, epilogue
+        # form) pairs overwrote blocks that had not been read out yet - the statistics are packed dot products now).  Every MFMA with
+        # an a[...] destination is one of the source's literal statements: destination = third source, aligned to a block, inside the
+        # literal range.
+        mf = re.findall(r"v_mfma_f32_32x32x16_\w+\s+([av]\[\d+:\d+\]),\s*\S+,\s*\S+,\s*([av]\[\d+:\d+\]|\S+)", body)
+        a_dst = [(d.rstrip(","), c) for d, c in mf if d.startswith("a")]
+        for d, c in a_dst:
+            lo = int(re.match(r"a\[(\d+):", d).group(1))
+            assert d == c and lo % 16 == 0 and lo < 16 * literal_blocks, (name, d, c)
+        # ... and nothing else names an accumulation register at all (gfx950 loads could target them directly)
+        for line in bodies[name]:
+            if re.search(r"[\s,]a(\[\d+:\d+\]|\d+)\b", line) and not re.search(r"^\s*(v_mfma_|v_accvgpr_)", line.strip()):
+                raise AssertionError((name, "accumulation register outside the source's statements", line.strip()))
+

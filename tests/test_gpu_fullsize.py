@@ -136,6 +136,48 @@ def test_unet_forward_at_the_metric_configuration_bf16():
     assert rel_err(got, want) < 1.5e-1
 
 
+def test_random_tile_assignments_at_the_metric_configuration():
+    """Tile fuzzing (r04, scripts/debug/fuzz_tiles_fullsize.py): the autotuner's choice differs from run to run on close calls, so
+    EVERY eligible (tile, K splits) pair of every signature has to be right, not just the usual winner.  Ten forwards with one random
+    eligible pair per signature each (seeded), eager, against the oracle golden.  This is the test that found the row-statistics
+    accumulators of the hand-scheduled tiles in live accumulation registers (tile 47 without a residual: error 0.04-0.10 of max)."""
+    import random
+    net = _fullsize_product(DT)
+    net.enable_graph(False)
+    want = torch.load(os.path.join(HERE, "golden", "unet_fullsize_16x64x64.pt"))["out"].float()
+    i = fullsize_inputs(16, 64)
+    dev = lambda x: x.to(DT).cuda()
+    args = (dev(i["sample"]), i["t"], dev(i["text"]), dev(i["cond"]), dev(i["mask"]))
+    rng = random.Random(2024)
+    fixed = {}
+
+    class NoCache(dict):
+        def get(self, k, default=None):
+            return None
+
+    def pick(lib, d, stream, key, rows, devc):
+        if key not in fixed:
+            c = ops._tile_candidates(d, rows)
+            fixed[key] = rng.choice(c) if c else (-1, 0)
+        return fixed[key]
+
+    keep = (ops._tile_cache, ops._autotune)
+    ops._load_default_tile_cache()
+    ops._tile_cache, ops._autotune = NoCache(), pick
+    worst = []
+    try:
+        with torch.no_grad():
+            for it in range(10):
+                fixed.clear()
+                got = net(*args, motion=i["motion"]).sample.float().cpu()
+                e, m = rel_err(got, want), ((got - want) ** 2).mean().item()
+                worst.append(e)
+                assert torch.isfinite(got).all() and e < 3e-2 and m < 1e-3, (it, e, m, sorted(fixed.items(), key=str))
+    finally:
+        ops._tile_cache, ops._autotune = keep
+    print(f"random tile assignments: max-normalised errors {[round(x, 4) for x in worst]}")
+
+
 def test_unet_forward_at_the_rgba_configuration_16x48x48():
     """BASELINE.json configs[4] runs the same UNet3D at 16 frames x 384 x 384 = 48 x 48 latents: full
     architecture, CFG batch 2, graph on, against the oracle golden tests/golden/unet_fullsize_16x48x48.pt."""
