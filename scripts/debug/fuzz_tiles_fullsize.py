@@ -1,7 +1,7 @@
 """Tile fuzzing at the metric configuration (r04): every aa_conv_gemm call of the full-size UNet3D forward runs with a RANDOM eligible
 (tile, K splits) pair instead of the autotuner's choice; the forward must match the oracle golden for every assignment.  Eager
 iterations draw per call; graph iterations draw one assignment per signature, capture, replay twice.  A failing iteration prints its
-assignment (signature -> choice) so that the offending tile can be bisected.  Usage: fuzz_tiles_fullsize.py [eager iters] [graph iters] [seed]"""
+assignment (signature -> choice) so that the offending tile can be bisected.  Usage: fuzz_tiles_fullsize.py [eager iters] [graph iters] [seed] [fp16|bf16|svd]"""
 import os
 import random
 import sys
@@ -18,16 +18,31 @@ from util import FULL_UNET, fullsize_inputs, fullsize_oracle, rel_err  # noqa: E
 n_eager = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n_graph = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rng = random.Random(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
-DT = torch.float16
-want = torch.load(os.path.join(ROOT, "tests", "golden", "unet_fullsize_16x64x64.pt"))["out"].float()
-_, state = fullsize_oracle()
-i = fullsize_inputs(16, 64)
-net = UNet3DConditionModel(**FULL_UNET).eval()
-net.load_state_dict(state)
-del state
-net = net.to(DT).cuda()
+MODE = sys.argv[4] if len(sys.argv) > 4 else "fp16"          # fp16 | bf16 (the UNet3D step) | svd (BASELINE configs[3], fp16)
+DT = torch.bfloat16 if MODE == "bf16" else torch.float16
+TOL_E, TOL_M = (1.5e-1, 1e-2) if MODE == "bf16" else (3e-2, 1e-3)
 dev = lambda x: x.to(DT).cuda()
-args = (dev(i["sample"]), i["t"], dev(i["text"]), dev(i["cond"]), dev(i["mask"]))
+if MODE == "svd":
+    from animate_anything_amd.svd_unet import UNetSpatioTemporalConditionModel
+    from util import FULL_SVD_UNET, fullsize_svd_oracle, svd_unet_inputs
+    want = torch.load(os.path.join(ROOT, "tests", "golden", "svd_unet_fullsize_14x72x128.pt"))["out"].float()
+    TOL_M = 1e-3 * max((want ** 2).mean().item(), 1.0)
+    _, state = fullsize_svd_oracle()
+    i = svd_unet_inputs(2, 14, 72, 128)
+    net = UNetSpatioTemporalConditionModel(**FULL_SVD_UNET).eval()
+    net.load_state_dict(state)
+    del state
+    net = net.to(DT).cuda()
+    args, kwargs = (dev(i["sample"]), i["t"], dev(i["text"]), i["ids"].cuda()), {}
+else:
+    want = torch.load(os.path.join(ROOT, "tests", "golden", "unet_fullsize_16x64x64.pt"))["out"].float()
+    _, state = fullsize_oracle()
+    i = fullsize_inputs(16, 64)
+    net = UNet3DConditionModel(**FULL_UNET).eval()
+    net.load_state_dict(state)
+    del state
+    net = net.to(DT).cuda()
+    args, kwargs = (dev(i["sample"]), i["t"], dev(i["text"]), dev(i["cond"]), dev(i["mask"])), dict(motion=i["motion"])
 
 
 class NoCache(dict):
@@ -52,7 +67,7 @@ def pick(lib, d, stream, key, rows, devc):
 def check(tag, got):
     got = got.float().cpu()
     e, m = rel_err(got, want), ((got - want) ** 2).mean().item()
-    bad = not (e < 3e-2 and m < 1e-3) or not torch.isfinite(got).all()
+    bad = not (e < TOL_E and m < TOL_M) or not torch.isfinite(got).all()
     print(f"{tag}: rel_err {e:.4f} mse {m:.3g} {'FAIL' if bad else 'ok'}", flush=True)
     return bad
 
@@ -65,7 +80,7 @@ with torch.no_grad():
     for it in range(n_eager):
         log.clear()
         fixed.clear()
-        got = net(*args, motion=i["motion"]).sample
+        got = net(*args, **kwargs).sample
         torch.cuda.synchronize()
         fails += check(f"eager {it}", got)
         for k, c in log:                                     # (every iteration: passing ones clear a choice)
@@ -75,14 +90,14 @@ with torch.no_grad():
         log.clear()
         fixed.clear()
         ops._tile_cache = NoCache()
-        net(*args, motion=i["motion"])                       # eager pass draws (and logs) a choice per signature
+        net(*args, **kwargs)                       # eager pass draws (and logs) a choice per signature
         assign = {}
         for k, c in log:
             assign.setdefault(k, c)                          # first draw per signature wins
         ops._tile_cache = dict(assign)
         net.enable_graph()
         for rep in range(2):
-            got = net(*args, motion=i["motion"]).sample
+            got = net(*args, **kwargs).sample
         torch.cuda.synchronize()
         if check(f"graph {it}", got):
             fails += 1

@@ -14,6 +14,8 @@ tail -3 $OUT/gpu_tests.log
 timeout 600 python scripts/debug/fuzz_tiles_fullsize.py 80 6 11 > $OUT/fuzz.log 2>&1; echo "tile fuzz rc=$? $(grep -c ' ok' $OUT/fuzz.log) ok $(grep -c FAIL $OUT/fuzz.log) fail" >> $OUT/summary.log
 AA_TICKETS=1 timeout 600 python scripts/debug/fuzz_tiles_fullsize.py 60 4 12 > $OUT/fuzz_tickets.log 2>&1; echo "tile fuzz (tickets) rc=$? $(grep -c ' ok' $OUT/fuzz_tickets.log) ok $(grep -c FAIL $OUT/fuzz_tickets.log) fail" >> $OUT/summary.log
 AA_LN_RAW=1 timeout 600 python scripts/debug/fuzz_tiles_fullsize.py 40 2 13 > $OUT/fuzz_lnraw.log 2>&1; echo "tile fuzz (raw LN statistics) rc=$? $(grep -c ' ok' $OUT/fuzz_lnraw.log) ok $(grep -c FAIL $OUT/fuzz_lnraw.log) fail" >> $OUT/summary.log
+timeout 600 python scripts/debug/fuzz_tiles_fullsize.py 40 3 14 bf16 > $OUT/fuzz_bf16.log 2>&1; echo "tile fuzz (bf16) rc=$? $(grep -c ' ok' $OUT/fuzz_bf16.log) ok $(grep -c FAIL $OUT/fuzz_bf16.log) fail" >> $OUT/summary.log
+timeout 900 python scripts/debug/fuzz_tiles_fullsize.py 40 3 15 svd > $OUT/fuzz_svd.log 2>&1; echo "tile fuzz (svd) rc=$? $(grep -c ' ok' $OUT/fuzz_svd.log) ok $(grep -c FAIL $OUT/fuzz_svd.log) fail" >> $OUT/summary.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.log
 tail -1 $OUT/smoke.log
 timeout 900 python bench.py --gemm-breakdown $OUT/gemm_breakdown.txt > $OUT/bench.json 2>$OUT/bench.err; echo "bench rc=$?" >> $OUT/summary.log
