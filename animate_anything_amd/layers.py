@@ -13,6 +13,8 @@ from __future__ import annotations
 from dataclasses import dataclass, replace
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -72,6 +74,11 @@ class _Packed:
 
 LN_FOLD = True       # BasicTransformerBlock: LayerNorm folded into the contraction that consumes it (ops.pack_weight(ln=...)), the row
                      # statistics taken from the epilogue of the contraction that produced the tensor; False = LayerNorm kernels
+# ... norm3 -> GEGLU as well: the fold costs the GEGLU projection 10 % at the 64x64 level (two accumulator blocks per output block to
+# start and to scale: 3.29 -> 3.61 ms per step there, +0.07 / +0.03 ms at the next levels) and saves the LayerNorm kernels in front
+# (0.36 / 0.10 / 0.03 ms) plus 1/3 of the finalize launches: an A/B on one box gave 64.57 / 64.63 ms with, 64.80 / 64.72 ms without
+# (profiles/r04q_*).  On (equal time, 3.4 GB / step less traffic); AA_LN_FOLD_FF=0 switches it off.
+LN_FOLD_FF = os.environ.get("AA_LN_FOLD_FF", "1") == "1"
 UPSAMPLE_AS_PARITY_CONVS = True      # Upsample2D at exactly x2: four 2x2 convolutions (ops.pack_upsample2x_weights); False = the 3x3 gather form
 
 
@@ -417,12 +424,13 @@ class BasicTransformerBlock(nn.Module):
             g = replace(g, clips=g.clips * dup)
         ln2 = None if st is None else (self.norm2, st)
         xin = x if ln2 is not None else self.norm2.tokens(x)
+        fold_ff = fold and LN_FOLD_FF
         if self.attn2.is_cross:
             kv = self.attn2.text_kv(text)
-            r = self.attn2.cross_tokens(xin, x, g, kv, text_len, ln=ln2, row_stats=fold)
+            r = self.attn2.cross_tokens(xin, x, g, kv, text_len, ln=ln2, row_stats=fold_ff)
         else:
-            r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, row_stats=fold)
-        x, st = r if fold else (r, None)
+            r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, row_stats=fold_ff)
+        x, st = r if fold_ff else (r, None)
         if st is not None:
             return self.ff.tokens(x, residual=x, ln=(self.norm3, st))
         return self.ff.tokens(self.norm3.tokens(x), residual=x)

@@ -92,7 +92,8 @@ def test_cfg_shared_prefix_matches_full_batch(emu):
     assert rel_err(outs[0], outs[1]) < 2e-3
 
 
-def test_layernorm_fold_replaces_the_layernorm_kernels(emu, monkeypatch):
+@pytest.mark.parametrize("fold_ff", [False, True])
+def test_layernorm_fold_replaces_the_layernorm_kernels(emu, monkeypatch, fold_ff):
     """layers.LN_FOLD: with a tile that emits row statistics forced onto every contraction it fits (the 128 x 128 hand-scheduled
     tile), the transformer blocks of the UNet run WITHOUT LayerNorm launches where the producer emitted statistics, and the
     result equals the LayerNorm-kernel form of the same network (and the oracle)."""
@@ -126,6 +127,7 @@ def test_layernorm_fold_replaces_the_layernorm_kernels(emu, monkeypatch):
     lib.aa_set_tile_override(47)                       # preference: taken wherever the packed width is a multiple of 128
     try:
         monkeypatch.setattr(layers, "LN_FOLD", True)
+        monkeypatch.setattr(layers, "LN_FOLD_FF", fold_ff)       # norm3 -> GEGLU folded as well (off by default: measured slower)
         folded = run()
         n_ln_fold, n_folded = calls["ln"], calls["folded"]
         monkeypatch.setattr(layers, "LN_FOLD", False)
