@@ -31,11 +31,13 @@ __host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring, i
     return cgd_lds_bytes(bm, bn, bk, ring) + (cgx_ln_ok(bk, wm, wn, per_cu) ? wm * wn * 2048 : 0);
 }
 
-// Tiles whose K-split launches can finish inside the kernel (AaConvGemm.tickets): the second epilogue instance needs registers - one
-// wave per SIMD (512 per lane), or the 128 x 128 tiles (64 accumulation registers).  With 128 literal accumulation registers next to
-// 128 VGPRs hipcc parks values in accumulation registers it believes free (tests/test_abi.py counts v_accvgpr_write: r04 build).
+// Tiles whose K-split launches can finish inside the kernel (AaConvGemm.tickets): the ones the small-M levels split along K - 128 x 128
+// (two workgroups per CU, 64 accumulation registers) and 192 x 256.  The finish is a second instance of every epilogue form: it is
+// compiled into these three tiles only (in all of them it doubled the library and added two minutes to the build, for a path that
+// measured slower than the reduce launch), and never into tiles with 128 literal accumulation registers next to 128 VGPRs, where the
+// extra pressure makes hipcc park values in accumulation registers it believes free (tests/test_abi.py counts v_accvgpr_write).
 __host__ __device__ constexpr bool cgx_ticket_ok(int bm, int bn, int wm, int wn, int per_cu) {
-    return (wm * wn * per_cu + 3) / 4 == 1 || (bm / wm / 32) * (bn / wn / 32) <= 4;
+    return (bm / wm / 32) * (bn / wn / 32) <= 4 || (bm == 192 && bn == 256 && (wm * wn * per_cu + 3) / 4 == 1);
 }
 
 // DP3 / DP0 / DP1: LDS-DMA pieces (per wave) of the tile after next issued under sub-step 3 of a K step and under

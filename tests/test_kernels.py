@@ -460,7 +460,7 @@ def test_layernorm_fold_through_split_k_and_producers_that_cannot_emit(backend):
         z = ops.conv_gemm(y, ops.pack_weight(w1, b1, ln=(gamma, beta, 1e-5)), ops.linear_geom(M), ln_stats=st)
         ops.USE_TICKETS = False
         _, none1 = ops.conv_gemm(y, ops.pack_weight(w1, b1), ops.linear_geom(M), row_stats=True)
-        ops.USE_TICKETS = True                    # (r04) a K split that finishes inside the kernel runs the usual epilogue: statistics included
+        ops.USE_TICKETS, ops.FORCE_TILE = True, 46          # (r04) a K split that finishes inside the kernel runs the usual epilogue: statistics included
         v, some = ops.conv_gemm(y, ops.pack_weight(w1, b1), ops.linear_geom(M), row_stats=True)
     finally:
         ops.K_SPLITS, ops.FORCE_TILE, ops.USE_TICKETS = 0, -1, True
@@ -554,8 +554,8 @@ def test_explicit_k_splits(backend, cfg, splits):
     close(y, ref)
 
 
-@pytest.mark.parametrize("cfg,splits,form", [(36, 3, "residual"), (39, 2, "rowvec"), (46, 4, "silu"), (47, 5, "plain"), (48, 3, "rowbias"),
-                                              (49, 3, "rowvec_residual"), (41, 4, "residual"), (42, 2, "plain"), (37, 3, "mapped")])
+@pytest.mark.parametrize("cfg,splits,form", [(46, 3, "residual"), (47, 2, "rowvec"), (46, 4, "silu"), (47, 5, "plain"), (48, 3, "rowbias"),
+                                              (48, 3, "rowvec_residual"), (47, 4, "residual"), (46, 2, "plain"), (47, 3, "mapped")])
 def test_k_split_finishes_inside_the_kernel(backend, cfg, splits, form):
     """AaConvGemm.tickets (ABI 106): the last workgroup of a tile to arrive sums the partials in split order and runs the epilogue -
     no reduce launch.  Every epilogue form a split call can carry, against fp32 torch, against the reduce-launch form of the same
@@ -601,6 +601,7 @@ def test_k_split_finishes_inside_the_kernel(backend, cfg, splits, form):
             y = y.reshape(n, h, 2, w, 2, N)[:, :, 1, :, 0].reshape(-1, N)
         return y, counts
 
+    # (tiles 46 / 47 / 48 carry the in-kernel finish: the ones the small-M levels split along K - conv_gemm_x.h cgx_ticket_ok)
     y1, c1 = run(True)
     assert c1[0] == 1 and c1[1] == 0 and c1[2] > 0, c1          # one launch, no reduce launch, one counter per workgroup of grid.x
     tk = ops._ticket_array(nhwc(x))
