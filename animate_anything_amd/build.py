@@ -54,7 +54,124 @@ def build(force=False, verbose=False, probe=False, ablate=0):
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
         objs = list(pool.map(compile_one, jobs))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+    # The hand-scheduled kernels keep their accumulators under literal register names hipcc does not manage: whether a build is sound
+    # depends on what THIS compiler did around them, so the code-object audit is part of the build, and the compiler that
+    # produced the library is recorded next to it.
+    if not ablate and os.environ.get("AA_BUILD_AUDIT", "1") != "0":
+        problems = audit_x_kernels(LIB)
+        info = {"hipcc": subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().split("\n"),
+                "flags": flags, "audit": "ok" if not problems else problems}
+        import json
+        with open(LIB[:-3] + ".buildinfo.json", "w") as f:
+            json.dump(info, f, indent=1)
+        if problems:
+            os.replace(LIB, LIB + ".rejected")
+            raise RuntimeError("libaa_mi355.so: the code-object audit of the hand-scheduled kernels failed (library moved to "
+                               + LIB + ".rejected):\n  " + "\n  ".join(str(p_) for p_ in problems[:8]))
     return LIB
+
+
+LLVM_TOOLS = "/opt/rocm/lib/llvm/bin"
+
+
+def device_code_objects(lib_path, out_dir):
+    """The gfx950 code objects inside the library: one clang offload bundle per translation unit (csrc/aa_api.hip and the groups of
+    csrc/aa_tiles.hip), written to `out_dir`; returns their paths."""
+    import struct
+    data = open(lib_path, "rb").read()
+    out, start = [], 0
+    while True:
+        i = data.find(b"__CLANG_OFFLOAD_BUNDLE__", start)
+        if i < 0:
+            break
+        start = i + 24
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        if not 0 < n < 16:
+            continue
+        off = i + 32
+        for _ in range(n):
+            o, s_, ln = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            name = data[off:off + ln].decode(errors="replace")
+            off += ln
+            if "gfx950" in name and s_ > 0:
+                p = os.path.join(out_dir, f"dev{len(out)}.co")
+                with open(p, "wb") as f:
+                    f.write(data[i + o:i + o + s_])
+                out.append(p)
+    return out
+
+
+def audit_x_kernels(lib_path):
+    """Audit of the hand-scheduled contraction kernels (csrc/kernels/conv_gemm_x.h) in a built library; returns a list of problems
+    (empty = sound).  Those kernels name their accumulators a[0:255] literally; hipcc does not know the registers are live, so it must
+    neither spill (scratch) nor touch accumulation registers itself (cdna guide 5.7 item 4).  Per kernel: no private segment, no
+    VGPR spills, a register count that fits its waves per SIMD, exactly the v_accvgpr traffic the source writes (16 initialising
+    writes per literal block and site, whole-block reads per read-out site), every MFMA with an a[...] destination one of the source's
+    literal statements (destination = third source, aligned to a block, inside the literal range - round 4 had the MFMA builtin of
+    the row-statistics epilogue reuse literal blocks), and no other instruction naming an accumulation register."""
+    import re
+    import shutil
+    import tempfile
+    if not shutil.which(os.path.join(LLVM_TOOLS, "llvm-objdump")):
+        return ["llvm-objdump / llvm-readelf not found under " + LLVM_TOOLS + ": the library cannot be audited"]
+    problems = []
+    with tempfile.TemporaryDirectory() as tmp:
+        cos = device_code_objects(lib_path, tmp)
+        if not cos:
+            return ["no gfx950 code object in " + lib_path]
+        run = lambda *a: subprocess.run(list(a), capture_output=True, text=True, check=True).stdout
+        notes = "".join(run(os.path.join(LLVM_TOOLS, "llvm-readelf"), "--notes", co) for co in cos)
+        dis = "".join(run(os.path.join(LLVM_TOOLS, "llvm-objdump"), "-d", "--no-show-raw-insn", co) for co in cos)
+    meta = {}
+    for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
+        meta[m.group(2)] = tuple(int(m.group(k)) for k in (1, 3, 4, 5))
+    xk = {k: v for k, v in meta.items() if "conv_gemm_x_kernel" in k}
+    if len(xk) < 16:                                        # 8 tiles x {fp16, bf16} at the very least
+        problems.append(f"only {len(xk)} hand-scheduled kernels found")
+    bodies, cur = {}, None
+    for line in dis.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            bodies[cur] = []
+        elif cur is not None:
+            bodies[cur].append(line)
+    for name, (agpr, scratch, vgpr, spills) in sorted(xk.items()):
+        bad = lambda what: problems.append(f"{name}: {what}")
+        if scratch or spills:
+            bad(f"scratch {scratch} bytes, {spills} VGPR spills")
+        m = re.search(r"x_kernelI\w+?Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        wm, wn, per_cu = int(m.group(3)), int(m.group(4)), int(m.group(10))
+        waves_per_simd = wm * wn * per_cu // 4             # 1: the whole 512-register file per lane; 2: half of it
+        if vgpr > 512 // waves_per_simd:
+            bad(f"{vgpr} registers per lane at {waves_per_simd} waves per SIMD")
+        body = "\n".join(bodies.get(name, []))
+        literal_blocks = agpr // 16
+        if literal_blocks not in (4, 8, 12, 15, 16):
+            bad(f"{agpr} accumulation registers")
+            continue
+        # written by the source only: started from the bias (or a folded LayerNorm's terms) at the K loop prologue / empty K range
+        # (the BK = 64 prologue has two sites, tiles that can start from a folded LayerNorm two forms per site)
+        writes = len(re.findall(r"v_accvgpr_write", body))
+        if writes % (16 * literal_blocks) or not 2 <= writes // (16 * literal_blocks) <= 8:
+            bad(f"{writes} v_accvgpr_write for {literal_blocks} literal blocks (hipcc parked values in accumulation registers)")
+        # read-out sites (split-K partials, the general epilogue, its branch-free forms, the in-kernel K-split finish) read whole blocks
+        reads = len(re.findall(r"v_accvgpr_read", body))
+        if not 2 * 16 * literal_blocks <= reads <= 32 * 16 * literal_blocks:
+            bad(f"{reads} v_accvgpr_read for {literal_blocks} literal blocks")
+        if "scratch_" in body:
+            bad("scratch access")
+        for d, c in re.findall(r"v_mfma_f32_32x32x16_\w+\s+([av]\[\d+:\d+\]),\s*\S+,\s*\S+,\s*([av]\[\d+:\d+\]|\S+)", body):
+            if d.startswith("a"):
+                lo = int(re.match(r"a\[(\d+):", d).group(1))
+                if d != c or lo % 16 or lo >= 16 * literal_blocks:
+                    bad(f"MFMA with accumulation-register destination {d} (third source {c}) is not one of the source's statements")
+        for line in bodies.get(name, []):
+            if re.search(r"[\s,]a(\[\d+:\d+\]|\d+)\b", line) and not re.search(r"^\s*(v_mfma_|v_accvgpr_)", line.strip()):
+                bad("accumulation register outside the source's statements: " + line.strip())
+                break
+    return problems
 
 
 if __name__ == "__main__":

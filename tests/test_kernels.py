@@ -412,7 +412,7 @@ def test_upsample2x_parity_convs_split_k(backend):
 def test_layernorm_folded_into_the_consuming_contraction(backend, M, C, ptile, ctile, geglu):
     """diffusers BasicTransformerBlock, norm -> projection (oracle/layers.py:219-224) without a LayerNorm kernel: the producing
     contraction (to_out + residual, hand-scheduled tile `ptile`) leaves partial (sum, sum of squares) per row of what it stores
-    (AaConvGemm.row_stats, computed on the matrix cores from the stored 16-bit values); the consuming one (Q|K|V / GEGLU, tile
+    (AaConvGemm.row_stats, packed dot products on the stored 16-bit values); the consuming one (Q|K|V / GEGLU, tile
     `ctile`: branch-free forms of the hand-scheduled tiles, or the general epilogue of a compiled tile) runs on the UN-normalised
     rows with W diag(gamma) and corrects rstd / mean / beta in its epilogue (AaConvGemm.ln_stats)."""
     a, w0, b0, r = rnd(M, 128, seed=201), rnd(C, 128, scale=0.2, seed=202), rnd(C, seed=203), rnd(M, C, seed=204) + 3.0    # rows with mean ~3, std ~2.5
