@@ -1,7 +1,7 @@
 """Tile fuzzing at the metric configuration (r04): every aa_conv_gemm call of the full-size UNet3D forward runs with a RANDOM eligible
 (tile, K splits) pair instead of the autotuner's choice; the forward must match the oracle golden for every assignment.  Eager
 iterations draw per call; graph iterations draw one assignment per signature, capture, replay twice.  A failing iteration prints its
-assignment (signature -> choice) so that the offending tile can be bisected.  Usage: fuzz_tiles_fullsize.py [eager iters] [graph iters] [seed] [fp16|bf16|svd]"""
+assignment (signature -> choice) so that the offending tile can be bisected.  Usage: fuzz_tiles_fullsize.py [eager iters] [graph iters] [seed] [fp16|bf16|rgba|svd]"""
 import os
 import random
 import sys
@@ -18,7 +18,7 @@ from util import FULL_UNET, fullsize_inputs, fullsize_oracle, rel_err  # noqa: E
 n_eager = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n_graph = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rng = random.Random(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
-MODE = sys.argv[4] if len(sys.argv) > 4 else "fp16"          # fp16 | bf16 (the UNet3D step) | svd (BASELINE configs[3], fp16)
+MODE = sys.argv[4] if len(sys.argv) > 4 else "fp16"          # fp16 | bf16 (the UNet3D step) | rgba (configs[4]: 48x48 latents) | svd (configs[3], fp16)
 DT = torch.bfloat16 if MODE == "bf16" else torch.float16
 TOL_E, TOL_M = (1.5e-1, 1e-2) if MODE == "bf16" else (3e-2, 1e-3)
 dev = lambda x: x.to(DT).cuda()
@@ -35,9 +35,10 @@ if MODE == "svd":
     net = net.to(DT).cuda()
     args, kwargs = (dev(i["sample"]), i["t"], dev(i["text"]), i["ids"].cuda()), {}
 else:
-    want = torch.load(os.path.join(ROOT, "tests", "golden", "unet_fullsize_16x64x64.pt"))["out"].float()
+    lat = 48 if MODE == "rgba" else 64
+    want = torch.load(os.path.join(ROOT, "tests", "golden", f"unet_fullsize_16x{lat}x{lat}.pt"))["out"].float()
     _, state = fullsize_oracle()
-    i = fullsize_inputs(16, 64)
+    i = fullsize_inputs(16, lat)
     net = UNet3DConditionModel(**FULL_UNET).eval()
     net.load_state_dict(state)
     del state
