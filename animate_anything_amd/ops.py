@@ -38,6 +38,7 @@ ATTN_FLAGS = 0        # experiments: AaAttention._pad (bit 0: s_setprio 1 around
 # the raw form removes 80 launches (-0.37 ms) and costs the K = 320 ... 1280 consumers 4-7 % (+0.7 ms: square root, reciprocal and the
 # sums sit in every tile's prologue) - the launch stays the default.
 LN_FINALIZE_LAUNCH = os.environ.get("AA_LN_RAW", "0") != "1"
+TILE_PICKER = None    # tests / scripts/debug: callable(signature key, [(tile, K splits), ...]) -> the pair a conv_gemm call runs with (GPU or emulator)
 LN_RAW_ANY_PARTS = False     # tests: let the consumer finalise any number of partial sums per row (a chain of dependent loads: +12-23 %)
 K_SPLITS = 0          # tests: explicit K split count for calls that are not autotuned (0 = library decides)
 # K-split launches of the hand-scheduled tiles can finish inside the kernel (AaConvGemm.tickets, ABI 106).  Measured on the step (r04g):
@@ -579,9 +580,12 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     if tk is not None:
         d.tickets, d.tickets_len = _ptr(tk), tk.numel()
     d.tile, d.k_splits = -1, K_SPLITS
-    if AUTOTUNE and x0.is_cuda and FORCE_TILE < 0 and K_SPLITS == 0:      # (explicit tile / split requests of tests and sweeps are not re-tuned)
-        key = (d.dtype, g.n_img, g.h_in, g.w_in, d.h_virt, d.w_virt, g.h_out, g.w_out, g.stride, pw.kh, pw.kw, c0, c1,
-               pw.n_out, d.geglu, residual is not None) + (("ln",) if ln_stats is not None else ()) + (("stats",) if row_stats else ())
+    key = (d.dtype, g.n_img, g.h_in, g.w_in, d.h_virt, d.w_virt, g.h_out, g.w_out, g.stride, pw.kh, pw.kw, c0, c1,
+           pw.n_out, d.geglu, residual is not None) + (("ln",) if ln_stats is not None else ()) + (("stats",) if row_stats else ())
+    if TILE_PICKER is not None and FORCE_TILE < 0 and K_SPLITS == 0:      # tile fuzzing (tests, scripts/debug): any eligible pair must be right
+        cands = _tile_candidates(d, g.rows)
+        d.tile, d.k_splits = TILE_PICKER(key, cands) if cands else (-1, 0)
+    elif AUTOTUNE and x0.is_cuda and FORCE_TILE < 0 and K_SPLITS == 0:    # (explicit tile / split requests of tests and sweeps are not re-tuned)
         _load_default_tile_cache()
         choice = _tile_cache.get(key)
         # the tuning launches write `out` repeatedly: only safe when no input of the call aliases it

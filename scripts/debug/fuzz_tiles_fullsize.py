@@ -46,23 +46,15 @@ else:
     args, kwargs = (dev(i["sample"]), i["t"], dev(i["text"]), dev(i["cond"]), dev(i["mask"])), dict(motion=i["motion"])
 
 
-class NoCache(dict):
-    def get(self, k, default=None):
-        return None
-
-
 log = []
 fixed = {}
 
 
-def pick(lib, d, stream, key, rows, devc):
-    if key in fixed:                                         # one draw per signature and iteration
-        return fixed[key]
-    c = ops._tile_candidates(d, rows)
-    choice = rng.choice(c) if c else (-1, 0)
-    fixed[key] = choice
-    log.append((key, choice))
-    return choice
+def pick(key, cands):
+    if key not in fixed:                                     # one draw per signature and iteration
+        fixed[key] = rng.choice(cands)
+        log.append((key, fixed[key]))
+    return fixed[key]
 
 
 def check(tag, got):
@@ -73,9 +65,7 @@ def check(tag, got):
     return bad
 
 
-ops._load_default_tile_cache()
-ops._tile_cache = NoCache()
-ops._autotune = pick
+ops.TILE_PICKER = pick
 fails = 0
 with torch.no_grad():
     for it in range(n_eager):
@@ -90,12 +80,10 @@ with torch.no_grad():
     for it in range(n_graph):
         log.clear()
         fixed.clear()
-        ops._tile_cache = NoCache()
-        net(*args, **kwargs)                       # eager pass draws (and logs) a choice per signature
-        assign = {}
-        for k, c in log:
-            assign.setdefault(k, c)                          # first draw per signature wins
-        ops._tile_cache = dict(assign)
+        ops.TILE_PICKER = pick
+        net(*args, **kwargs)                                 # eager pass draws (and logs) a choice per signature
+        assign = dict(fixed)
+        ops.TILE_PICKER = lambda key, cands, assign=assign: assign.get(key, cands[0])      # the capture replays the same assignment
         net.enable_graph()
         for rep in range(2):
             got = net(*args, **kwargs).sample
@@ -105,4 +93,5 @@ with torch.no_grad():
             for k, c in sorted(assign.items(), key=str):
                 print("   ", k, c)
         net.enable_graph(False)
+        ops.TILE_PICKER = pick
 print("failures:", fails)

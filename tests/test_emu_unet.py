@@ -139,3 +139,39 @@ def test_layernorm_fold_replaces_the_layernorm_kernels(emu, monkeypatch, fold_ff
     with torch.no_grad():
         want = ref(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
     assert rel_err(folded, want) < 3e-2 and rel_err(plain, want) < 3e-2 and rel_err(folded, plain) < 2e-2
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_tile_assignments_tiny_unet(emu, seed):
+    """Tile fuzzing on the emulator (the CPU twin of tests/test_gpu_fullsize.py::test_random_tile_assignments_at_the_metric_configuration,
+    ops.TILE_PICKER): every contraction of the tiny UNet runs on a random eligible tile of the library's table - compiled, halo-slab and
+    hand-scheduled ones, with and without row statistics / a folded LayerNorm - and the forward still matches the oracle.  (Register
+    allocation bugs of the real code object are the GPU test's and the build audit's business; this one covers the index arithmetic
+    of every tile x epilogue form the graph can reach.)"""
+    import random
+    from animate_anything_amd import ops
+    torch.manual_seed(0)
+    ref = oracle.UNet3DConditionModel(**TINY_UNET).eval()
+    state = seeded_state(ref)
+    ref.load_state_dict(state)
+    net = UNet3DConditionModel(**TINY_UNET).eval()
+    net.load_state_dict(state)
+    net = net.half()
+    i = unet_inputs(h=6, w=6, text_len=9)
+    rng = random.Random(seed)
+    used = {}
+
+    def pick(key, cands):
+        if key not in used:
+            used[key] = rng.choice(cands)
+        return used[key]
+    ops.TILE_PICKER = pick
+    try:
+        with torch.no_grad():
+            got = net(i["sample"].half(), i["t"], i["text"].half(), i["cond"].half(), i["mask"].half(), motion=i["motion"]).sample
+    finally:
+        ops.TILE_PICKER = None
+    with torch.no_grad():
+        want = ref(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
+    assert len({c[0] for c in used.values()}) >= 8, used          # a spread of tiles really ran
+    assert rel_err(got, want) < 3e-2, (rel_err(got, want), sorted(used.items(), key=str))

@@ -151,19 +151,12 @@ def test_random_tile_assignments_at_the_metric_configuration():
     rng = random.Random(2024)
     fixed = {}
 
-    class NoCache(dict):
-        def get(self, k, default=None):
-            return None
-
-    def pick(lib, d, stream, key, rows, devc):
+    def pick(key, cands):
         if key not in fixed:
-            c = ops._tile_candidates(d, rows)
-            fixed[key] = rng.choice(c) if c else (-1, 0)
+            fixed[key] = rng.choice(cands)
         return fixed[key]
 
-    keep = (ops._tile_cache, ops._autotune)
-    ops._load_default_tile_cache()
-    ops._tile_cache, ops._autotune = NoCache(), pick
+    ops.TILE_PICKER = pick
     worst = []
     try:
         with torch.no_grad():
@@ -174,7 +167,7 @@ def test_random_tile_assignments_at_the_metric_configuration():
                 worst.append(e)
                 assert torch.isfinite(got).all() and e < 3e-2 and m < 1e-3, (it, e, m, sorted(fixed.items(), key=str))
     finally:
-        ops._tile_cache, ops._autotune = keep
+        ops.TILE_PICKER = None
     print(f"random tile assignments: max-normalised errors {[round(x, 4) for x in worst]}")
 
 
