@@ -184,6 +184,34 @@ def test_tiny_svd_unet_matches_oracle(emu, text_len, pixel_major, monkeypatch):
     assert rel_err(got, want) < 1e-2
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_tiny_svd_unet_random_tile_assignments(emu, seed):
+    """Tile fuzzing on the emulator (ops.TILE_PICKER): every contraction of the tiny SVD UNet - spatio-temporal resnets with the
+    `acc_scale` blend epilogue, both transformer kinds, the row-vector context path - on a random eligible tile of the table."""
+    import random
+    ref, net = tiny_unet()
+    g = torch.Generator().manual_seed(7)
+    b, f, h, w = 2, 3, 4, 6
+    x, ctx = torch.randn(b, f, 9, h, w, generator=g), torch.randn(b, 1, 64, generator=g)
+    ids = torch.tensor([[6.0, 127.0, 0.02]]).repeat(b, 1)
+    rng, used = random.Random(seed), {}
+
+    def pick(key, cands):
+        if key not in used:
+            used[key] = rng.choice(cands)
+        return used[key]
+    ops.TILE_PICKER = pick
+    try:
+        with torch.no_grad():
+            got = net(x.half(), 1.2, ctx.half(), ids).sample
+    finally:
+        ops.TILE_PICKER = None
+    with torch.no_grad():
+        want = ref(x, 1.2, ctx, ids).sample
+    assert len({c[0] for c in used.values()}) >= 8, used
+    assert rel_err(got, want) < 1e-2, (rel_err(got, want), sorted(used.items(), key=str))
+
+
 def test_tiny_svd_unet_batch3_and_8_channels(emu):
     """h*w not a multiple of the batch (the general context-table attention instead of the row-vector blend) and the
     8-input-channel (no mask) model of the plain SVD checkpoint."""
