@@ -141,8 +141,8 @@ def test_layernorm_fold_replaces_the_layernorm_kernels(emu, monkeypatch, fold_ff
     assert rel_err(folded, want) < 3e-2 and rel_err(plain, want) < 3e-2 and rel_err(folded, plain) < 2e-2
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_random_tile_assignments_tiny_unet(emu, seed):
+@pytest.mark.parametrize("seed,splits,tickets", [(1, False, False), (2, False, False), (3, False, False), (4, True, False), (5, True, True)])
+def test_random_tile_assignments_tiny_unet(emu, seed, splits, tickets):
     """Tile fuzzing on the emulator (the CPU twin of tests/test_gpu_fullsize.py::test_random_tile_assignments_at_the_metric_configuration,
     ops.TILE_PICKER): every contraction of the tiny UNet runs on a random eligible tile of the library's table - compiled, halo-slab and
     hand-scheduled ones, with and without row statistics / a folded LayerNorm - and the forward still matches the oracle.  (Register
@@ -163,14 +163,18 @@ def test_random_tile_assignments_tiny_unet(emu, seed):
 
     def pick(key, cands):
         if key not in used:
-            used[key] = rng.choice(cands)
+            tile, sp = rng.choice(cands)
+            if splits:                                          # `splits`: random K splits on top (the library clamps them to the K steps there
+                sp = rng.choice((0, 0, 2, 3, 5))                #  are and ignores them where a call cannot split): partials + reduce launch, or -
+            used[key] = (tile, sp)                              #  `tickets` - the finish inside the kernel on the tiles that carry it
         return used[key]
-    ops.TILE_PICKER = pick
+    ops.TILE_PICKER, keep = pick, ops.USE_TICKETS
+    ops.USE_TICKETS = tickets
     try:
         with torch.no_grad():
             got = net(i["sample"].half(), i["t"], i["text"].half(), i["cond"].half(), i["mask"].half(), motion=i["motion"]).sample
     finally:
-        ops.TILE_PICKER = None
+        ops.TILE_PICKER, ops.USE_TICKETS = None, keep
     with torch.no_grad():
         want = ref(i["sample"], i["t"], i["text"], i["cond"], i["mask"], motion=i["motion"]).sample
     assert len({c[0] for c in used.values()}) >= 8, used          # a spread of tiles really ran
