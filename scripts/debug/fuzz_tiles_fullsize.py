@@ -1,7 +1,7 @@
 """Tile fuzzing at the metric configuration (r04): every aa_conv_gemm call of the full-size UNet3D forward runs with a RANDOM eligible
 (tile, K splits) pair instead of the autotuner's choice; the forward must match the oracle golden for every assignment.  Eager
 iterations draw per call; graph iterations draw one assignment per signature, capture, replay twice.  A failing iteration prints its
-assignment (signature -> choice) so that the offending tile can be bisected.  Usage: fuzz_tiles_fullsize.py [eager iters] [graph iters] [seed] [fp16|bf16|rgba|svd]"""
+assignment (signature -> choice) so that the offending tile can be bisected.  Usage: fuzz_tiles_fullsize.py [eager iters] [graph iters] [seed] [fp16|bf16|rgba|svd] [probability of an arbitrary K split]"""
 import os
 import random
 import sys
@@ -50,9 +50,15 @@ log = []
 fixed = {}
 
 
+SPLIT_P = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0    # probability of an arbitrary K split count on top of the drawn tile
+
+
 def pick(key, cands):
     if key not in fixed:                                     # one draw per signature and iteration
-        fixed[key] = rng.choice(cands)
+        tile, sp = rng.choice(cands)
+        if SPLIT_P and rng.random() < SPLIT_P:               # (the library clamps the count to the K steps and ignores it where a call cannot split)
+            sp = rng.choice((2, 3, 4, 7))
+        fixed[key] = (tile, sp)
         log.append((key, fixed[key]))
     return fixed[key]
 
