@@ -57,7 +57,13 @@ def build(force=False, verbose=False, probe=False, ablate=0):
     # The hand-scheduled kernels keep their accumulators under literal register names hipcc does not manage: whether a build is sound
     # depends on what THIS compiler did around them, so the code-object audit is part of the build, and the compiler that
     # produced the library is recorded next to it.
-    if not ablate and os.environ.get("AA_BUILD_AUDIT", "1") != "0":
+    import shutil
+    have_tools = shutil.which(os.path.join(LLVM_TOOLS, "llvm-objdump")) and shutil.which(os.path.join(LLVM_TOOLS, "llvm-readelf"))
+    if not ablate and os.environ.get("AA_BUILD_AUDIT", "1") != "0" and not have_tools:
+        import json
+        with open(LIB[:-3] + ".buildinfo.json", "w") as f:       # (a toolchain without the LLVM binutils: built, NOT audited - say so)
+            json.dump({"flags": flags, "audit": "skipped: llvm-objdump / llvm-readelf not found under " + LLVM_TOOLS}, f, indent=1)
+    elif not ablate and os.environ.get("AA_BUILD_AUDIT", "1") != "0":
         problems = audit_x_kernels(LIB)
         info = {"hipcc": subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().split("\n"),
                 "flags": flags, "audit": "ok" if not problems else problems}
