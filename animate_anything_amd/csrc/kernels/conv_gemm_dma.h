@@ -189,7 +189,7 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
             auto ln_apply = [&](float (&x)[16], const int) __attribute__((always_inline)) {       // the accumulation started from the fold's
               if constexpr (LNF) {                                                                  // rank-1 terms (conv_gemm_x.h): x *= rstd
 #pragma unroll
-                for (int e = 0; e < 16; ++e) x[e] *= ln_a[i];
+                for (int e = 0; e < 16; ++e) x[e] *= ln_a[i];       // (scalar on purpose: as packed pairs this cost the GEGLU epilogue 0.9 k clk per tile - r04pk probe)
               }
             };
             if constexpr (LNF) ln_apply(v, j);

@@ -330,7 +330,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
                     constexpr int i = decltype(i_)::value;
                     f32x16 v;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = fmaf(ln_nmean[i], cs[e], bp[e] * ln_sd[i]);
+                    for (int e = 0; e < 16; e += 2) {           // packed fp32 pairs: half the multiply / fma issues of this VALU-bound prologue
+                        const f32x2 t = f32x2{bp[e], bp[e + 1]} * f32x2{ln_sd[i], ln_sd[i]};          // (r04 phase probe: the scalar form was 512 of its ~770 instructions)
+                        const f32x2 r = __builtin_elementwise_fma(f32x2{ln_nmean[i], ln_nmean[i]}, f32x2{cs[e], cs[e + 1]}, t);
+                        v[e] = r[0]; v[e + 1] = r[1];
+                    }
                     acc_init<i * NI + j>(af, v);
                 });
               }
