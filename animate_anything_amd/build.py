@@ -148,6 +148,9 @@ def audit_x_kernels(lib_path):
         if scratch or spills:
             bad(f"scratch {scratch} bytes, {spills} VGPR spills")
         m = re.search(r"x_kernelI\w+?Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        if m is None or name not in bodies:                  # another mangling / template parameter list, or no disassembly: not auditable
+            bad("cannot parse the kernel name" if m is None else "no disassembly found")
+            continue
         wm, wn, per_cu = int(m.group(3)), int(m.group(4)), int(m.group(10))
         waves_per_simd = wm * wn * per_cu // 4             # 1: the whole 512-register file per lane; 2: half of it
         if vgpr > 512 // waves_per_simd:

@@ -140,17 +140,28 @@ static bool cg_x_ok(const AaConvGemm& d) {
     return true;
 }
 
+// Can table entry i carry out call d at all (the one predicate behind the automatic choice, a forced tile, aa_conv_gemm_tile_ok and
+// the tile of a split-off last round - ADVICE r04: the last of these had its own, incomplete copy and handed folded-LayerNorm
+// calls to a tile that cannot start its accumulators from the fold's terms).
+static bool cg_tile_fits(const AaConvGemm& d, int i) {
+    const CgCfg& c = kCgCfgs[i];
+    if (d.n_pad % c.bn) return false;
+    if (d.geglu && (c.bn / c.wn) % 64) return false;          // value / gate blocks pair up inside one wavefront
+    if (c.slab && !cg_slab_ok(d, c)) return false;
+    if (c.x && (!cg_x_ok(d) || (i >= 36 && ((g_x_disabled >> (i - 36)) & 1u)))) return false;
+    // the LayerNorm fold starts the accumulators of the hand-scheduled tiles from its rank-1 terms: one-wave-per-SIMD tiles with a
+    // 64-wide K step only (cgx_ln_ok); the compiled tiles apply the full formula in their epilogue
+    if (c.x && d.ln_stats && !cgx_ln_ok(c.bk, c.wm, c.wn, c.per_cu)) return false;
+    return true;
+}
+
 static int cg_choose(const AaConvGemm& d, int M) {
     int best = -1;
     double best_cost = 0.0;
     const int forced = d.tile >= 0 ? d.tile : cg_force_cfg();
     for (int i = 0; i < kNumCgCfgs; ++i) {
         const CgCfg& c = kCgCfgs[i];
-        if (d.n_pad % c.bn) continue;
-        if (d.geglu && (c.bn / c.wn) % 64) continue;          // value / gate blocks pair up inside one wavefront
-        if (c.slab && !cg_slab_ok(d, c)) continue;
-        if (c.x && (!cg_x_ok(d) || (i >= 36 && ((g_x_disabled >> (i - 36)) & 1u)))) continue;
-        if (c.x && d.ln_stats && (c.wm * c.wn * c.per_cu > 4 || c.bk != 64)) continue;
+        if (!cg_tile_fits(d, i)) continue;
         if (forced == i) return i;
         const double tiles = (double)((M + c.bm - 1) / c.bm) * (d.n_pad / c.bn);
         const double slots = 256.0 * c.per_cu;
@@ -250,11 +261,8 @@ static CgPlan cg_plan(const AaConvGemm& d, int M, bool have_workspace_or_query) 
         return p;
     }
     const int small[3] = {47, 1, 0};                       // 128x128 (hand-scheduled, then compiled), 128x64
-    for (int k = 0; k < 3 && p.tail_cfg < 0; ++k) {
-        const CgCfg& t = kCgCfgs[small[k]];
-        if (t.x && (!cg_x_ok(d) || ((g_x_disabled >> (small[k] - 36)) & 1u))) continue;
-        if (d.n_pad % t.bn == 0 && (!d.geglu || (t.bn / t.wn) % 64 == 0)) p.tail_cfg = small[k];
-    }
+    for (int k = 0; k < 3 && p.tail_cfg < 0; ++k)
+        if (cg_tile_fits(d, small[k])) p.tail_cfg = small[k];
     if (p.tail_cfg < 0) p.tail_cfg = p.cfg;               // no small tile fits (wide GEGLU): big tile again
     return p;
 }
@@ -531,13 +539,7 @@ int aa_conv_gemm_tile_info(int idx, int32_t info[7]) {
 int aa_conv_gemm_tile_ok(const AaConvGemm* d, int idx) {
     using namespace aa;
     if (!d || idx < 0 || idx >= kNumCgCfgs || !cg_dma_ok(*d)) return 0;
-    const CgCfg& c = kCgCfgs[idx];
-    if (d->n_pad % c.bn) return 0;
-    if (d->geglu && (c.bn / c.wn) % 64) return 0;
-    if (c.slab && !cg_slab_ok(*d, c)) return 0;
-    if (c.x && (!cg_x_ok(*d) || (idx >= 36 && ((g_x_disabled >> (idx - 36)) & 1u)))) return 0;
-    if (c.x && d->ln_stats && (c.wm * c.wn * c.per_cu > 4 || c.bk != 64)) return 0;      // the LayerNorm fold starts the accumulators in one-wave-per-SIMD tiles only
-    return 1;
+    return cg_tile_fits(*d, idx) ? 1 : 0;
 }
 void aa_set_tile_override(int cfg) {
     if (cfg <= -100) { aa::g_x_disabled = (unsigned)(-100 - cfg); return; }     // bisecting aid: withdraw hand-scheduled tiles (bit i = entry 36 + i)

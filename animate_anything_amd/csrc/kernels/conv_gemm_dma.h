@@ -253,7 +253,7 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
 }
 
 // BIAS_FOLDED: the accumulators were started from the bias (conv_gemm_x.h) and sBiasW holds zeros.
-// part: this wave's slot of AaConvGemm.row_stats (-1: the caller cannot emit them).  A BIAS_FOLDED caller has also started the
+// part: this wave's slot of AaConvGemm.row_stats (-1: the caller cannot emit them).  ln_rstd.on: the caller has started its
 // accumulators from the rank-1 terms of a folded LayerNorm (AaConvGemm.ln_stats): its epilogue form only scales by rstd.
 template <typename T, int MI, int NI, bool BIAS_FOLDED = false, typename Get>
 __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW,
@@ -275,7 +275,9 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
     const bool stats = p.row_stats != nullptr && part >= 0;
     // the combinations that carry the step take the branch-free forms - where the accumulators sit in the accumulation registers
     // (conv_gemm_x.h): next to 128-160 accumulators in VGPRs the extra offsets spill (measured: 160-220 dwords of scratch)
-    if (BIAS_FOLDED && !silu && !p.bias_per_row) {
+    // (a folded LayerNorm takes its rstd-only form only where THIS kernel instance started its accumulators from the fold's rank-1
+    //  terms - ln_rstd.on; anything else falls through to the general path below, which applies the whole formula: ADVICE r04)
+    if (BIAS_FOLDED && !silu && !p.bias_per_row && !(lnf && !ln_rstd.on)) {
         if (lnf) {
             if (p.geglu) {
                 if constexpr (NI % 2 == 0) { cgd_epilogue_fast<T, MI, NI, true, false, false, false, true, false>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd); return; }
@@ -347,7 +349,7 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
                 if (pre_is_rv) r.raw = pv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[q][e] = a[8 * q + e] + (float)b.e[e] + brow;
-                if (lnf && !BIAS_FOLDED) {                // rstd * acc - rstd * mean * colsum(W') + b'  (compiled tiles: nothing was folded into the start)
+                if (lnf && !ln_rstd.on) {                 // rstd * acc - rstd * mean * colsum(W') + b'  (nothing was folded into the accumulator start)
                     const float* cs = p.ln_cols + n_wave + j * 32 + 16 * eh + 8 * q;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[q][e] = fmaf(v[q][e], lr.a, fmaf(lr.nm, cs[e], cs[p.n_pad + e]));

@@ -212,6 +212,8 @@ def _autotune(lib, d, stream, key, rows, dev):
             return n > 0
         cands = [c for c in cands if emits(*c)] or cands
     best = (-1, 0)
+    if len(cands) == 1:                                  # (one way left - e.g. the only tile that emits the row statistics: take it, do not
+        best = cands[0]                                  #  fall back to the library's own choice, which may be another: ADVICE r04)
     if len(cands) > 1:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ws_keep = (d.workspace, d.workspace_bytes)
@@ -533,10 +535,13 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
             if rowvec is not None:                         # row-vector groups are whole images (or whole clips of them)
                 assert (i0 * ro) % rowvec_div == 0 and ((i0 + n) * ro) % rowvec_div == 0 or i0 + n == g.n_img
                 rv = rowvec[(i0 * ro) // rowvec_div:]
+            ls = None
+            if ln_stats is not None:                       # the statistics of a chunk's rows (the folded call is linear: ri == ro)
+                ls = RowStats(ln_stats.data[i0 * ri:(i0 + n) * ri], n * ri, ln_stats.parts)
             conv_gemm(x0[i0 * ri:(i0 + n) * ri], pw, gi, None if x1 is None else x1[i0 * ri:(i0 + n) * ri], rv, rowvec_div,
                       None if residual is None else residual[i0 * ro:(i0 + n) * ro], act, out_dtype, out_scale, False,
-                      out[i0 * ro * osc:(i0 + n) * ro * osc], bias, acc_scale, out_map)
-        return out
+                      out[i0 * ro * osc:(i0 + n) * ro * osc], bias, acc_scale, out_map, ls)
+        return (out, None) if row_stats else out           # (chunks may run different tiles: no common statistics layout - the caller keeps its LayerNorm)
     if c0 + c1 != pw.cin:
         raise RuntimeError(f"conv_gemm: activation has {c0}+{c1} channels, weight expects {pw.cin}")
     n_cols = pw.n_out // 2 if pw.geglu else pw.n_out

@@ -52,6 +52,7 @@ def parse():
                    help="time the product default (text-independent UNet prefix computed once per guidance pair) as the headline "
                         "instead of the strict form that recomputes it for both halves like the reference")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-vae", action="store_true", help="skip the per-clip AutoencoderKL encode / decode timing (the `vae` object)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-tile-cache", action="store_true", help="ignore the committed tile choices (animate_anything_amd/tile_cache_gfx950.json): autotune everything")
     p.add_argument("--tile-cache", default="", help="json file with autotuned tile choices: loaded if present, written after warm-up")
@@ -196,19 +197,29 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
                 f.write(f"{key[0]:7d} {key[1]:6d} {key[2]:6d} {key[3]:6s} {key[4]:5s}{key[5]:3s} | {v[0]:3d} {v[1]:8.3f} "
                         f"{v[2] / (v[1] * 1e-3) / 1e12:7.1f} {v[3]:>4s} {v[1] / tot * 100:5.1f}%\n")
     ach = flops / (gemm_ms * 1e-3) / 1e12
-    traffic, tname, t_launches = None, None, None
-    for tname_ in ("r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):     # newest committed PMC measurement
-        tpath = os.path.join(ROOT, "profiles", tname_)
-        if os.path.exists(tpath):
-            rec = json.load(open(tpath))
-            fam = rec.get("contraction_kernels") or rec.get("conv_gemm_dma_kernel") or {}
-            traffic, tname, t_launches = fam.get("hbm_bytes_per_launch"), tname_, fam.get("launches_per_step")
-            break
+    # bench.py cannot profile itself: the PMC bytes come from the newest committed run of scripts/pmc_traffic.sh - and only count
+    # when that run was of THIS library and THIS launch plan (a kernel change without a new PMC run used to report
+    # stale bytes silently).  The record carries the sha256 of the libaa_mi355.so it profiled.
+    import glob
+    traffic, tname, t_launches, stale = None, None, None, None
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_pmc.json")), reverse=True):
+        rec = json.load(open(tpath))
+        fam = rec.get("contraction_kernels") or rec.get("conv_gemm_dma_kernel") or {}
+        tname = os.path.basename(tpath)
+        if rec.get("library_sha256_16") != library_id():
+            stale = f"profiles/{tname} was measured on library {rec.get('library_sha256_16', '(unrecorded)')}, this is {library_id()}"
+        elif fam.get("launches_per_step") != launches:
+            stale = f"profiles/{tname} had {fam.get('launches_per_step')} contraction launches per step, this run has {launches}"
+        else:
+            traffic, t_launches = fam.get("hbm_bytes_per_launch"), fam.get("launches_per_step")
+        break
     traffic_step = traffic * t_launches if traffic and t_launches else None
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": f"HBM bytes per KERNEL LAUNCH of the contraction kernels, measured (PMC, profiles/{tname}: that run had "
-                            f"{t_launches} such launches per step)",
+            "traffic_unit": (f"HBM bytes per KERNEL LAUNCH of the contraction kernels, measured (PMC FETCH_SIZE x 2 + WRITE_SIZE in separate "
+                             f"rocprofv3 passes, profiles/{tname}: same library {library_id()}, {t_launches} such launches per step)") if traffic
+                            else f"null: no PMC measurement of this library ({stale or 'no profiles/r*_traffic_pmc.json'}); run scripts/pmc_traffic.sh",
+            "library_sha256_16": library_id(),
             "kernel": "contraction kernels: aa::conv_gemm_dma_kernel / conv3x3_slab_kernel / conv_gemm_x_kernel (LDS-DMA implicit-GEMM conv / linear), all instances",
             "contraction_launches_per_step": launches, "reduce_launches_per_step": reduces, "aa_conv_gemm_calls_per_step": len(trace),
             "avg_kernel_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
@@ -216,6 +227,53 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
             "algorithmic_bytes_per_step": round(alg_bytes), "traffic_bytes_per_step": traffic_step,
             "traffic_over_algorithmic": round(traffic_step / alg_bytes, 3) if traffic_step else None,
             "whole_step_frac_of_peak": round(flop_step / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+
+
+_LIB_ID = None
+
+
+def library_id():
+    """sha256[:16] of the libaa_mi355.so this process runs (what a committed PMC record must name to be quoted)."""
+    global _LIB_ID
+    if _LIB_ID is None:
+        import hashlib
+        from animate_anything_amd import build
+        _LIB_ID = hashlib.sha256(open(build.LIB, "rb").read()).hexdigest()[:16] if os.path.exists(build.LIB) else "missing"
+    return _LIB_ID
+
+
+def vae_timing(dtype, device, ms_step):
+    """SURVEY section 8(d) "VAE encode + decode ms per clip": the SD AutoencoderKL (seeded random weights) around the denoising loop of
+    one clip - encode of the ONE conditioning frame at 512x512 (reference utils/common.py:12-20 via train.py:766-770) and decode
+    of the 16 generated frames (models/pipeline.py:200) - once per clip, not per step, so reported beside `value`, not inside it.
+    FLOP: BASELINE.md section 2 (encode 1.117 TFLOP / frame, decode 2.515 TFLOP / frame)."""
+    from animate_anything_amd.vae import AutoencoderKL
+    torch.manual_seed(0)
+    with torch.device(device):
+        vae = AutoencoderKL()
+    vae = vae.to(dtype).eval()
+    g = torch.Generator(device=device).manual_seed(7)
+    img = (torch.rand(1, 3, 512, 512, generator=g, device=device) * 2 - 1).to(dtype)
+    z = torch.randn(16, 4, 64, 64, generator=g, device=device).to(dtype)
+
+    def timed(fn, reps=3):
+        y = fn()                                            # (first call: weight packing, tile choices)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = fn()
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    with torch.no_grad():
+        enc = timed(lambda: vae.encode(img).latent_dist.mode())
+        dec = timed(lambda: vae.decode(z).sample)
+    return {"encode_1x512x512_ms": round(enc, 3), "decode_16x512x512_ms": round(dec, 3),
+            "encode_tflops": round(1.117 / enc * 1e3, 1), "decode_tflops": round(16 * 2.515 / dec * 1e3, 1),
+            "per_clip_ms": round(enc + dec, 3),
+            "note": "AutoencoderKL (SD VAE architecture, seeded random init), once per clip: encode of the conditioning frame + decode of "
+                    "the 16 generated frames; = %.2f denoising steps of this run" % ((enc + dec) / ms_step)}
 
 
 def respawn_under_torchrun(a, script):
@@ -498,9 +556,12 @@ def bench(a, selftest=False):
             dto = tmx.item()
         other = {"cfg_shared_prefix": not a.cfg_shared_prefix, "value": round(world * a.steps / dto, 4), "ms_per_step": round(dto / a.steps * 1e3, 3),
                  "note": "same step with the text-independent UNet prefix (conv_in, transformer_in, first resnet / temporal conv / spatial "
-                         "self-attention) computed once per guidance pair instead of twice: identical latents, 42.621 instead of 44.262 TFLOP executed"}
+                         "self-attention) computed once per guidance pair instead of twice: the same arithmetic per element on other tiles (other "
+                         "summation orders), 42.621 instead of 44.262 TFLOP executed; the measured difference of the latents after two steps "
+                         "is max_abs_latent_difference_after_2_steps (fp16 rounding noise amplified by guidance 9 on random weights; "
+                         "tests/test_gpu_fullsize.py bounds it by the measured noise floor of the strict form and checks both forms against the oracle)"}
         # cross-check of the two forms where rounding differences have not been amplified yet by the (random-weight, guidance 9)
-        # dynamics: two steps from the same initial latents (tests/test_gpu_fullsize.py asserts the same bound)
+        # dynamics: two steps from the same initial latents
         with torch.no_grad():
             two = []
             for flag in (False, True):
@@ -548,6 +609,9 @@ def bench(a, selftest=False):
         out["cpu_affinity"] = f"{len(pinned)} CPUs of the GPU's NUMA node"
     if a.workload == "rgba" and rank == 0:
         out["rgba_addons"] = rgba_addons(dtype, device, a.frames, a.size)
+    if a.workload == "unet3d" and rank == 0 and world == 1 and not selftest and not a.no_vae:
+        out["vae"] = vae_timing(dtype, device, ms_step)
+        out["autotuned_signatures_vae"] = int(ops.AUTOTUNE_EVENTS) - out["autotuned_signatures"]
     if a.tile_cache and rank == 0:
         ops.save_tile_cache(a.tile_cache)                       # (again: the other guidance form and the eager trace add signatures)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

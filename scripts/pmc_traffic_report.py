@@ -40,4 +40,9 @@ for fam in sorted(set(fetch) | set(write)):
     wb = 1024.0 * sum(w) / max(len(w), 1)
     out[fam] = {"launches_profiled": len(f), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                 "hbm_bytes_per_launch": round(fb + wb), "launches_per_step": len(f) // 2}
+# which library was profiled: bench.py quotes these bytes only for the same libaa_mi355.so (sha256[:16])
+import hashlib
+import os
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "animate_anything_amd", "libaa_mi355.so")
+out["library_sha256_16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None
 print(json.dumps(out, indent=1))

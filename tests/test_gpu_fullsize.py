@@ -432,11 +432,86 @@ def test_full_size_vae_decode_and_encode_one_frame():
         assert rel_err(got_z, want_z) < 2e-2
 
 
-def test_cfg_shared_prefix_equals_full_batch_at_the_metric_configuration():
-    """LatentToVideoPipeline.denoise under guidance computes the text-independent UNet prefix once per pair: ONE full-size
-    step both ways (same seeded weights / inputs as bench.py) must give the same latents to fp16 rounding."""
+def _denoise_steps(net, i, ts, shared, guidance=9.0):
+    """The product loop (LatentToVideoPipeline.denoise) over timesteps `ts` on the seeded full-size inputs; returns the fp32
+    latents after every step (CPU)."""
     from animate_anything_amd.pipeline import LatentToVideoPipeline
     from animate_anything_amd.schedulers import DPMSolverMultistepScheduler
+    dt = net.dtype
+    pipe = LatentToVideoPipeline(vae=None, unet=net, scheduler=DPMSolverMultistepScheduler())
+    pipe.cfg_shared_prefix = shared
+    pipe.scheduler.set_timesteps(25)
+    assert [int(t) for t in pipe.scheduler.timesteps][: len(ts)] == list(ts)
+    per_step = []
+    with torch.no_grad():
+        pipe.denoise(i["sample"][:1].cuda().float(), i["text"].to(dt).cuda(), i["cond"][:1].to(dt).cuda(), i["mask"].to(dt).cuda(),
+                     [3.0], list(ts), guidance, callback=lambda _k, _t, x: per_step.append(x.float().cpu().clone()), callback_steps=1)
+    return per_step
+
+
+def test_three_steps_against_the_oracle_at_the_metric_configuration():
+    """the product's DEFAULT loop (text-independent UNet prefix computed once per guidance pair) and the strict
+    loop (both guidance halves in full, what bench.py times), three steps of the 25-step DPM-Solver++ schedule at guidance 9 on the
+    full architecture at 16 x 64 x 64, each compared AFTER EVERY STEP with the oracle pipeline loop
+    (tests/golden/pipeline_fullsize_16x64x64_3steps.pt = oracle.LatentToVideoPipeline.__call__, which test_reference_pin.py holds
+    equal to the reference's own `LatentToVideoPipeline.__call__`, models/pipeline.py:163-198).
+      * per step and form: latent MSE < 1e-3 (north star), MSE / mean(want^2) < 1e-3, max-normalised error < 3e-2;
+      * the shared-prefix form is no further from the oracle than 1.5 x the strict form (+ 1e-3 of the range);
+      * the two forms differ from EACH OTHER by no more than 3 x the fp16 noise floor, measured here as the strict form run twice
+        under two random tile assignments (other tiles = other summation orders, nothing else) - not by a constant (round 4
+        doubled a constant when the test failed)."""
+    import random
+    fixture = os.path.join(HERE, "golden", "pipeline_fullsize_16x64x64_3steps.pt")
+    if not os.path.exists(fixture):
+        pytest.skip("golden not generated (tests/golden/make_fullsize_multistep_golden.py)")
+    gold = torch.load(fixture)
+    want, ts = gold["latents"].float(), [int(t) for t in gold["timesteps"]]
+    assert gold["guidance_scale"] == 9.0 and want.shape[1:] == (1, 4, 16, 64, 64)
+    i = fullsize_inputs(16, 64)
+    net = _fullsize_product(DT)
+    strict, shared = _denoise_steps(net, i, ts, False), _denoise_steps(net, i, ts, True)
+    # the noise floor: the strict form, eager, every contraction on a random eligible (tile, K split) pair - two assignments
+    net.enable_graph(False)
+    floor_runs = []
+    for seed in (11, 12):
+        rng, fixed = random.Random(seed), {}
+        ops.TILE_PICKER = lambda key, cands: fixed.setdefault(key, rng.choice(cands))
+        try:
+            floor_runs.append(_denoise_steps(net, i, ts, False))
+        finally:
+            ops.TILE_PICKER = None
+    lines = []
+    for k in range(len(ts)):
+        w = want[k]
+        rng_ = w.abs().max().item()
+        stat = lambda x: (((x - w) ** 2).mean().item(), ((x - w) ** 2).mean().item() / (w ** 2).mean().item(), (x - w).abs().max().item() / rng_)
+        (m_s, n_s, e_s), (m_h, n_h, e_h) = stat(strict[k]), stat(shared[k])
+        pair = (strict[k] - shared[k]).abs().max().item() / rng_
+        floor = (floor_runs[0][k] - floor_runs[1][k]).abs().max().item() / rng_
+        e_f = max(stat(floor_runs[0][k])[2], stat(floor_runs[1][k])[2])
+        lines.append(f"step {k + 1} (t={ts[k]}, |x|max {rng_:.3f}): strict MSE {m_s:.3g} norm {n_s:.3g} max {e_s:.3g} | shared-prefix MSE {m_h:.3g} "
+                     f"norm {n_h:.3g} max {e_h:.3g} | strict vs shared {pair:.3g} | strict under two random tile assignments {floor:.3g} "
+                     f"(vs oracle {e_f:.3g})")
+        print(lines[-1])
+        for x in (strict[k], shared[k], floor_runs[0][k], floor_runs[1][k]):
+            assert torch.isfinite(x).all()
+        assert m_s < 1e-3 and m_h < 1e-3 and n_s < 1e-3 and n_h < 1e-3, lines[-1]
+        assert e_s < 3e-2 and e_h < 3e-2 and e_f < 3e-2, lines[-1]
+        assert e_h <= 1.5 * e_s + 1e-3, lines[-1]
+        assert pair <= 3.0 * floor + 1e-3, lines[-1]
+    out = os.environ.get("AA_PARITY_REPORT")
+    if out:
+        with open(out, "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+def test_cfg_shared_prefix_equals_full_batch_at_the_metric_configuration():
+    """LatentToVideoPipeline.denoise under guidance computes the text-independent UNet prefix once per pair: two full-size steps
+    both ways on bench.py's weights (torch default init under seed 0, not the oracle's state) must agree to the fp16 noise floor
+    of this very computation - measured, not assumed: the strict form run twice with every contraction on a random eligible
+    (tile, K split) pair.  (Round 4 bounded the difference by a constant and doubled it when the test failed; against the oracle
+    both forms are checked by test_three_steps_against_the_oracle_at_the_metric_configuration.)"""
+    import random
     from animate_anything_amd.unet3d import UNet3DConditionModel
     torch.manual_seed(0)
     with torch.device("cuda"):
@@ -447,20 +522,20 @@ def test_cfg_shared_prefix_equals_full_batch_at_the_metric_configuration():
                 p_.normal_(0.0, 0.02)
     net = net.to(DT).eval()
     i = fullsize_inputs(16, 64)
-    lat = i["sample"][:1].cuda().float()
-    outs = []
-    for shared in (False, True):
-        pipe = LatentToVideoPipeline(vae=None, unet=net, scheduler=DPMSolverMultistepScheduler())
-        pipe.cfg_shared_prefix = shared
-        pipe.scheduler.set_timesteps(25)
-        ts = [int(t) for t in pipe.scheduler.timesteps][:2]
-        with torch.no_grad():
-            outs.append(pipe.denoise(lat, i["text"].to(DT).cuda(), i["cond"][:1].to(DT).cuda(), i["mask"].to(DT).cuda(), [3.0], ts, 9.0))
-    a, b = outs[0].float(), outs[1].float()
+    ts = [951, 913]
+    a, b = _denoise_steps(net, i, ts, False)[-1], _denoise_steps(net, i, ts, True)[-1]
+    runs = []
+    for seed in (21, 22):
+        rng, fixed = random.Random(seed), {}
+        ops.TILE_PICKER = lambda key, cands: fixed.setdefault(key, rng.choice(cands))
+        try:
+            runs.append(_denoise_steps(net, i, ts, False)[-1])
+        finally:
+            ops.TILE_PICKER = None
+    scale = max(1.0, a.abs().max().item())
+    err = (a - b).abs().max().item() / scale
+    floor = (runs[0] - runs[1]).abs().max().item() / scale
+    print(f"strict vs shared-prefix after 2 steps: {err:.4g} of the latent range; strict vs strict under two random tile assignments: {floor:.4g}")
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
-    err = (a - b).abs().max().item()
-    # The two forms run different row counts through the first blocks - other tiles, other summation orders - and two steps at
-    # guidance 9 with random weights amplify that rounding noise: 1.5-2.1 % of the latent range here over the rounds (0.130 of 6.34 in
-    # r04, `bench.py` reports the same quantity as other_form.max_abs_latent_difference_after_2_steps), against 100 % for a wrong
-    # prefix.  The bound was 2 % until the r04 statistics rewrite moved the noise from 0.12 to 0.13.
-    assert err < 4e-2 * max(1.0, a.abs().max().item()), (err, a.abs().max().item())
+    assert err <= 3.0 * floor + 1e-3, (err, floor)
+    assert err < 0.25                   # (a wrong prefix is an error of the size of the range)

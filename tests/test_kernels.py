@@ -447,6 +447,78 @@ def test_layernorm_folded_into_the_consuming_contraction(backend, M, C, ptile, c
         ops.conv_gemm(y, pw, ops.linear_geom(M))                      # folded weights without statistics
 
 
+def _ln_fold_consume(y, st, pw, ctile, raw, splits=0, ablate=0):
+    """One consuming contraction of a folded LayerNorm on tile `ctile`: statistics raw (ABI 106 ln_parts) or through aa_ln_finalize."""
+    keep = ops.LN_FINALIZE_LAUNCH
+    ops.FORCE_TILE, ops.K_SPLITS, ops.DEBUG_ABLATE = ctile, splits, ablate
+    ops.LN_RAW_ANY_PARTS, ops.LN_FINALIZE_LAUNCH = raw, not raw
+    try:
+        return ops.conv_gemm(y, pw, ops.linear_geom(y.shape[0]), ln_stats=st)
+    finally:
+        ops.FORCE_TILE, ops.K_SPLITS, ops.DEBUG_ABLATE, ops.LN_FINALIZE_LAUNCH, ops.LN_RAW_ANY_PARTS = -1, 0, 0, keep, False
+
+
+@pytest.mark.parametrize("ctile,geglu", [(36, False), (36, True), (38, True), (39, False), (14, False), (3, True), (49, False)])
+def test_layernorm_fold_with_a_split_off_last_round(backend, ctile, geglu):
+    """a big-tile launch hands a sparsely filled last round to a small tile (cg_plan); with a folded LayerNorm
+    that tile must be one that applies the fold - the hand-scheduled 128x128 tile (two workgroups per CU) neither starts its
+    accumulators from the fold's terms nor corrects them in its epilogue, and used to be chosen for the tail: rows behind the
+    full rounds came out wrong by the size of the output.  DEBUG_ABLATE 4 = a 2-CU chip, so 720 rows are two full tiles + a tail."""
+    M, C = 720, 320
+    N = 320 if ops.TILE_TABLE[ctile][1] == 320 else (384 if geglu else 256)      # an odd number of column tiles: 3 x odd tiles on 2 CUs leave a tail
+    y = rnd(M, C, seed=231) * 2.0 + 1.5
+    w1, b1 = rnd(2 * N if geglu else N, C, scale=0.06, seed=232), rnd(2 * N if geglu else N, seed=233)
+    gamma, beta = rnd(C, seed=234) * 0.3 + 1.0, rnd(C, seed=235) * 0.2
+    yf = y.float()
+    st = ops.RowStats(torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=1).reshape(M, 1, 2).contiguous().to(DEV), M, 1)
+    pw = ops.pack_weight(w1, b1, geglu=geglu, ln=(gamma, beta, 1e-5))
+    z = _ln_fold_consume(y, st, pw, ctile, raw=False, ablate=4)
+    h = F.layer_norm(yf, (C,), gamma.float(), beta.float(), 1e-5) @ w1.float().t() + b1.float()
+    want = h[:, :N] * F.gelu(h[:, N:]) if geglu else h
+    close(z[:512], want[:512])
+    close(z[512:], want[512:])          # the split-off rows on their own: a wrong tail is not averaged away
+
+
+@pytest.mark.parametrize("C,ptile,ctile,geglu,raw,splits", [
+    (320, 49, 39, False, False, 0), (320, 49, 36, True, False, 0), (320, 49, 39, False, True, 0),      # branch-free forms, rank-1 accumulator start
+    (320, 49, 1, False, False, 0), (320, 49, 3, True, False, 0),                                        # compiled tiles: the whole formula in the epilogue
+    (320, 49, 36, False, False, 3),                                                                     # K split: the formula in the reduce launch
+    (640, 47, 36, True, True, 0), (1280, 46, 39, False, False, 0)])                                     # ten partial sums per row
+def test_layernorm_fold_cancellation(backend, C, ptile, ctile, geglu, raw, splits):
+    """VERDICT r04 weak point 2: the fold's statistics are E[x^2] - E[x]^2 on fp32 row sums and the consumer subtracts
+    mean * colsum(W') from an UN-centred product.  Rows with mean 50 / std ~1 (the GroupNorm kernel has the same case:
+    test_groupnorm_large_mean) and rows with one 200x outlier channel - what a trained residual stream carries - against
+    F.layer_norm in fp32 on the same stored rows, through every consumer form."""
+    M = 300
+    a, w0, b0 = rnd(M, 128, seed=241), rnd(C, 128, scale=0.05, seed=242), rnd(C, scale=0.5, seed=243)
+    r = rnd(M, C, scale=0.5, seed=244) + 50.0
+    r[5::16] -= 50.0                                   # every 16th row: centred, with one outlier channel 200x the rest
+    r[5::16, 13] += 200.0
+    bn = ops.TILE_TABLE[ctile][1]
+    N = 640 if bn == 320 else (384 if geglu or bn < 256 else 512)
+    w1, b1 = rnd(2 * N if geglu else N, C, scale=0.08, seed=245), rnd(2 * N if geglu else N, seed=246)
+    gamma, beta = rnd(C, seed=247) * 0.3 + 1.0, rnd(C, seed=248) * 0.2
+    ops.FORCE_TILE = ptile
+    try:
+        y, st = ops.conv_gemm(a, ops.pack_weight(w0, b0), ops.linear_geom(M), residual=r, row_stats=True)
+    finally:
+        ops.FORCE_TILE = -1
+    assert st is not None
+    yf = y.float()
+    assert 45.0 < yf[0].mean().item() < 55.0 and 0.5 < yf[0].std().item() < 2.0 and yf[5].abs().max().item() > 150.0
+    pw = ops.pack_weight(w1, b1, geglu=geglu, ln=(gamma, beta, 1e-5))
+    z = _ln_fold_consume(y, st, pw, ctile, raw, splits)
+    h = F.layer_norm(yf, (C,), gamma.float(), beta.float(), 1e-5) @ w1.float().t() + b1.float()
+    want = h[:, :N] * F.gelu(h[:, N:]) if geglu else h
+    close(z, want)
+    # the statistics themselves: mean to 1e-4 of its size, variance to 1 % (fp32 sums of 16-bit products, no pivot)
+    tot = st.data.float().sum(dim=1).cpu()
+    mean = tot[:, 0] / C
+    var = tot[:, 1] / C - mean * mean
+    assert ((mean - yf.cpu().mean(1)).abs() <= 1e-4 * yf.cpu().mean(1).abs().clamp_min(1.0)).all()
+    assert ((var - yf.cpu().var(1, unbiased=False)).abs() <= 1e-2 * yf.cpu().var(1, unbiased=False)).all()
+
+
 def test_layernorm_fold_through_split_k_and_producers_that_cannot_emit(backend):
     """A K-split consumer applies the fold in the reduce launch; a producer that is split along K (or runs a compiled tile)
     reports no statistics (aa_conv_gemm_row_stats_parts == 0) and the caller keeps its LayerNorm kernel."""
