@@ -79,6 +79,13 @@ LN_FOLD = True       # BasicTransformerBlock: LayerNorm folded into the contract
 # (0.36 / 0.10 / 0.03 ms) plus 1/3 of the finalize launches: an A/B on one box gave 64.57 / 64.63 ms with, 64.80 / 64.72 ms without
 # (profiles/r04q_*).  On (equal time, 3.4 GB / step less traffic); AA_LN_FOLD_FF=0 switches it off.
 LN_FOLD_FF = os.environ.get("AA_LN_FOLD_FF", "1") == "1"
+# Transformer2DModel / TransformerTemporalModel end with  proj_out(ff_out(h) + x) + residual  (h = the GEGLU output, x = the block's
+# residual stream): two linear maps with only an addition between them.  Merged into ONE contraction over the channel-concatenated
+# sources [h | x] with the weights [Wp W2 | Wp] and the bias Wp b2 + bp (products in fp32, one rounding to the storage type - the
+# same kind of exact re-association as the LayerNorm fold): the same 2 M (4C + C) C multiply-adds, but the K = C projection - bound by
+# its three tensor passes and per-tile fixed costs, 420-730 TF/s - rides as 25 % more K on a K = 4C contraction that runs at 730-950,
+# and the block output is never written or re-read (-2 tensor passes, -30 launches per step).  AA_FF_PROJ_MERGE=0: the two calls.
+FF_PROJ_MERGE = os.environ.get("AA_FF_PROJ_MERGE", "1") == "1"
 UPSAMPLE_AS_PARITY_CONVS = True      # Upsample2D at exactly x2: four 2x2 convolutions (ops.pack_upsample2x_weights); False = the 3x3 gather form
 
 
@@ -389,8 +396,13 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim_out or dim)])
 
-    def tokens(self, x, residual, ln=None):
-        return self.net[2].tokens(self.net[0].tokens(x, ln=ln), residual=residual)
+    def tokens(self, x, residual, ln=None, tail=None):
+        """`tail` = (packed merged weights of _MergedTail, the transformer's outer residual): ff-out, `+ residual` and the
+        transformer's proj_out as one two-source contraction (FF_PROJ_MERGE)."""
+        h = self.net[0].tokens(x, ln=ln)
+        if tail is None:
+            return self.net[2].tokens(h, residual=residual)
+        return ops.conv_gemm(h, tail[0], ops.linear_geom(h.shape[0]), x1=residual, residual=tail[1])
 
 
 class BasicTransformerBlock(nn.Module):
@@ -404,7 +416,7 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.double_self_attention = double_self_attention
 
-    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0, dup: int = 1, x_stats=None):
+    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0, dup: int = 1, x_stats=None, tail=None):
         """`dup` > 1: x holds ONE copy of `dup` identical groups of clips (classifier-free guidance runs the same latents
         with two prompts, models/pipeline.py:165): the self-attention - which never sees the text - is computed once and
         its result replicated in front of the cross-attention; `g` describes the single copy.
@@ -432,11 +444,37 @@ class BasicTransformerBlock(nn.Module):
             r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, row_stats=fold_ff)
         x, st = r if fold_ff else (r, None)
         if st is not None:
-            return self.ff.tokens(x, residual=x, ln=(self.norm3, st))
-        return self.ff.tokens(self.norm3.tokens(x), residual=x)
+            return self.ff.tokens(x, residual=x, ln=(self.norm3, st), tail=tail)
+        return self.ff.tokens(self.norm3.tokens(x), residual=x, tail=tail)
 
 
-class Transformer2DModel(nn.Module):
+class _MergedTail:
+    """Mixin of the two transformer wrappers: the packed weights of  proj_out(ff_out(h) + x)  as one contraction over [h | x]."""
+    _mt = None
+    _mt_key = None
+
+    def _apply(self, fn, *a, **k):
+        self._mt = None
+        return super()._apply(fn, *a, **k)
+
+    def merged_tail(self):
+        ff_out = self.transformer_blocks[-1].ff.net[2]
+        w2, b2, wp, bp = ff_out.weight, ff_out.bias, self.proj_out.weight, self.proj_out.bias
+        hidden, dim = w2.shape[1], w2.shape[0]
+        if not FF_PROJ_MERGE or hidden % 64 or dim % 64 or wp.shape[1] != dim:       # (two-source K tiles must not straddle the sources)
+            return None
+        key = weights_key(w2, b2, wp, bp)
+        if self._mt is None or self._mt_key != key:
+            wpf = wp.detach().float()
+            w = torch.cat([wpf @ w2.detach().float(), wpf], dim=1)                  # [C_out, 4C + C]
+            b = (0.0 if bp is None else bp.detach().float()) + (0.0 if b2 is None else wpf @ b2.detach().float())
+            b = b if torch.is_tensor(b) else None
+            self._mt = ops.pack_weight(w.to(wp.dtype), None if b is None else b.to(wp.dtype))
+            self._mt_key = key
+        return self._mt
+
+
+class Transformer2DModel(_MergedTail, nn.Module):
     """diffusers Transformer2DModel(use_linear_projection=True)."""
 
     def __init__(self, heads, head_dim, in_channels, cross_attention_dim=1024, norm_num_groups=32):
@@ -451,14 +489,17 @@ class Transformer2DModel(nn.Module):
         """`dup` > 1 (see BasicTransformerBlock.tokens): x / g are the single copy, the result covers all `dup` groups."""
         h, st = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw), row_stats=True) if LN_FOLD else \
                 (self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw)), None)
+        outer = torch.cat([x] * dup) if dup > 1 else x
+        mt, last = self.merged_tail(), len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
-            h = blk.tokens(h, g, temporal=False, text=text, text_len=text_len, dup=dup if i == 0 else 1, x_stats=st if i == 0 else None)
+            h = blk.tokens(h, g, temporal=False, text=text, text_len=text_len, dup=dup if i == 0 else 1, x_stats=st if i == 0 else None,
+                           tail=(mt, outer) if mt is not None and i == last else None)
             if i == 0 and dup > 1:
                 g = replace(g, clips=g.clips * dup)
-        return self.proj_out.tokens(h, residual=torch.cat([x] * dup) if dup > 1 else x)
+        return h if mt is not None else self.proj_out.tokens(h, residual=outer)
 
 
-class TransformerTemporalModel(nn.Module):
+class TransformerTemporalModel(_MergedTail, nn.Module):
     """diffusers TransformerTemporalModel(double_self_attention=True): clip-wide
     GroupNorm, then a transformer whose sequences are the T frames of one pixel (strided rows)."""
 
@@ -474,6 +515,7 @@ class TransformerTemporalModel(nn.Module):
     def tokens(self, x, g: Grid):
         h, st = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw), row_stats=True) if LN_FOLD else \
                 (self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw)), None)
+        mt, last = self.merged_tail(), len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
-            h = blk.tokens(h, g, temporal=True, x_stats=st if i == 0 else None)
-        return self.proj_out.tokens(h, residual=x)
+            h = blk.tokens(h, g, temporal=True, x_stats=st if i == 0 else None, tail=(mt, x) if mt is not None and i == last else None)
+        return h if mt is not None else self.proj_out.tokens(h, residual=x)
