@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
     for (int e = 0; e < 16; ++e) minus_m[e] = 0.0f;
 
     const bool prio = (p._pad & 1) != 0;
+    const bool eager_max = (p._pad & 2) != 0;
     const int ntiles = (p.kv_len + KT - 1) / KT;
     const bool ragged = (p.kv_len & (KT - 1)) != 0;
     const int stages = attn_stages(p.kv_len);   // 3 (two tiles in flight ahead of the math) or 1 (single tile)
@@ -192,23 +193,28 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
                         if (key >= p.kv_len) sacc[kb][e] = -1.0e30f;
                     }
             }
-            // row max of (score - m): three-input maxima (v_max3_f32), independent chains per half block, then a tree
-            float mx[2 * KB];
+            // Row maximum of (score - m) over this tile: three-input maxima (v_max3_f32), independent chains per half block, a tree,
+            // one v_permlane32_swap for the other half-wave's keys.  Only the FIRST tile pays for it up front (it centres the
+            // softmax on its true row maximum); every later tile exponentiates against the running maximum straight away and looks
+            // at its maximum only if the sums say it has to (below): ~24 of a tile's ~130 vector instructions - this kernel is bound
+            // by them (32 quarter-rate v_exp_f32 + ~100 others per 16 MFMAs), not by the matrix pipe.
+            auto row_over = [&]() __attribute__((always_inline)) {
+                float mx[2 * KB];
 #pragma unroll
-            for (int c = 0; c < 2 * KB; ++c) {
-                const f32x16& a = sacc[c >> 1];
-                const int b = 8 * (c & 1);
-                const float m0 = fmaxf(fmaxf(a[b], a[b + 1]), a[b + 2]);
-                const float m1 = fmaxf(fmaxf(a[b + 3], a[b + 4]), a[b + 5]);
-                mx[c] = fmaxf(fmaxf(m0, m1), fmaxf(a[b + 6], a[b + 7]));
-            }
-            float mall = fmaxf(mx[0], mx[1]);
-            if constexpr (KB == 2) mall = fmaxf(fmaxf(mall, mx[2]), mx[3]);
-            const float over = wave_max_halves(mall);
-            if (kt == 0 || wave_any(over > AT_DEFER)) {
-                // move the maximum (rare after the first tiles): everything still at the old maximum - O, l and this tile's
-                // scores, which have NOT been exponentiated yet - is rescaled exactly once
-                const float delta = kt == 0 ? over : fmaxf(over, 0.0f);
+                for (int c = 0; c < 2 * KB; ++c) {
+                    const f32x16& a = sacc[c >> 1];
+                    const int b = 8 * (c & 1);
+                    const float m0 = fmaxf(fmaxf(a[b], a[b + 1]), a[b + 2]);
+                    const float m1 = fmaxf(fmaxf(a[b + 3], a[b + 4]), a[b + 5]);
+                    mx[c] = fmaxf(fmaxf(m0, m1), fmaxf(a[b + 6], a[b + 7]));
+                }
+                float mall = fmaxf(mx[0], mx[1]);
+                if constexpr (KB == 2) mall = fmaxf(fmaxf(mall, mx[2]), mx[3]);
+                return wave_max_halves(mall);
+            };
+            // move the maximum by `delta` (>= 0 per row; the first tile: its true maximum): everything still at the old maximum - O,
+            // l and this tile's scores - is rescaled exactly once
+            auto move_max = [&](const float delta, const bool first) __attribute__((always_inline)) {
                 m_run += delta;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) minus_m[e] = -m_run;
@@ -216,37 +222,60 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
                 for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) sacc[kb][e] -= delta;
-                if (kt != 0) {
+                if (!first) {
                     const float alpha = fast_exp2(-delta);
                     l_run *= alpha;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
                 }
-            }
+            };
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            f32x2 ps2[2 * KB];                                                          // packed partial row sums
-#pragma unroll
-            for (int c = 0; c < 2 * KB; ++c) ps2[c] = f32x2{0.0f, 0.0f};
             u32x4 pf[2 * KB];
+            // p = 2^(score - m) for this lane's keys -> the P^T operand registers; returns their sum
+            auto exponentiate = [&]() __attribute__((always_inline)) {
+                f32x2 ps2[2 * KB];                                                          // packed partial row sums
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
+                for (int c = 0; c < 2 * KB; ++c) ps2[c] = f32x2{0.0f, 0.0f};
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    Pack8<T> pk;
+                for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        f32x2 pe;
-                        pe[0] = fast_exp2(sacc[kb][8 * c + e]);                  // one v_exp per score
-                        pe[1] = fast_exp2(sacc[kb][8 * c + e + 1]);
-                        ps2[2 * kb + c] += pe;
-                        pk.e[e] = (T)pe[0];
-                        pk.e[e + 1] = (T)pe[1];
+                    for (int c = 0; c < 2; ++c) {
+                        Pack8<T> pk;
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            f32x2 pe;
+                            pe[0] = fast_exp2(sacc[kb][8 * c + e]);                  // one v_exp per score
+                            pe[1] = fast_exp2(sacc[kb][8 * c + e + 1]);
+                            ps2[2 * kb + c] += pe;
+                            pk.e[e] = (T)pe[0];
+                            pk.e[e + 1] = (T)pe[1];
+                        }
+                        pf[2 * kb + c] = pk.raw;
                     }
-                    pf[2 * kb + c] = pk.raw;
+                f32x2 pst = ps2[0] + ps2[1];
+                if constexpr (KB == 2) pst += ps2[2] + ps2[3];
+                return pst[0] + pst[1];
+            };
+            if (kt == 0) move_max(row_over(), true);
+            else if (eager_max) {                       // (A/B switch, AaAttention._pad bit 1: the round-2..4 form - every tile computes its maximum)
+                const float over = row_over();
+                if (wave_any(over > AT_DEFER)) move_max(fmaxf(over, 0.0f), false);
+            }
+            float psum = exponentiate();
+            // Lazy maximum (defer-max, round 5 form): the running maximum has to move only when some p would leave the range the
+            // deferral allows (p <= 2^AT_DEFER).  A lane's p's are non-negative, so "one of them exceeds 2^AT_DEFER" implies "their
+            // sum does" (and an overflowed p makes the sum inf, a NaN fails the comparison): the sum - needed anyway - is the whole
+            // check.  When it fires the tile's scores, untouched in their registers, are looked at after all; rows that are more than
+            // a bit above their maximum move it (so a flat run of p ~ 2..64 cannot fire tile after tile) and the tile is exponentiated
+            // again.  Rare: after the first tile has centred a row, later keys seldom beat it by 6 bits.
+            if (kt != 0 && !eager_max && wave_any(!(psum <= 64.0f))) {
+                static_assert(AT_DEFER == 6.0f, "the sum test above is 2^AT_DEFER");
+                const float over = row_over();
+                if (wave_any(over > 1.0f)) {
+                    move_max(fmaxf(over, 0.0f), false);
+                    psum = exponentiate();
                 }
-            f32x2 pst = ps2[0] + ps2[1];
-            if constexpr (KB == 2) pst += ps2[2] + ps2[3];
-            const float psum = pst[0] + pst[1];
+            }
             l_run += psum;
             // O^T += V^T P^T: chunk ch = 16 keys; this half-wave's 8 k-slots are keys 16ch + 4h + {0..3} and
             // 16ch + 8 + 4h + {0..3} (the order P^T's registers came out of the S^T accumulator layout)

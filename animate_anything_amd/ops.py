@@ -32,7 +32,7 @@ LAST_STAMPS = None
 GN_PLANS = None            # a list: groupnorm() appends (groups per workgroup, pieces per thread, parts, grid) or None per call
 MAX_OPERAND_BYTES = 1 << 31      # the contraction kernel's 32-bit operand offsets
 FORCE_TILE = -1       # tests / sweeps: >= 0 puts this tile-table index into AaConvGemm.tile of every conv_gemm call (strict: ineligible = error)
-ATTN_FLAGS = 0        # experiments: AaAttention._pad (bit 0: s_setprio 1 around the matrix clusters of the head_dim-64 kernel)
+ATTN_FLAGS = int(os.environ.get("AA_ATTN_FLAGS", "0"))   # experiments: AaAttention._pad (bit 0: s_setprio 1 around the matrix clusters of the head_dim-64 kernel; bit 1: the eager row maximum of rounds 2-4)
 # A folded LayerNorm's row statistics reach the consumer as aa_ln_finalize's per-row coefficients (one 4.7 us launch per consumer, 99 per
 # step) or raw (ABI 106 `ln_parts`: the consumer finalises 2 / 10 partial sums per row itself with independent loads).  Measured (r04h/i):
 # the raw form removes 80 launches (-0.37 ms) and costs the K = 320 ... 1280 consumers 4-7 % (+0.7 ms: square root, reciprocal and the

@@ -34,3 +34,18 @@ print("last replayed step by kernel family (launches, ms):")
 for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k:32s} {v[0]:5d} {v[1] / 1e6:8.3f}")
 print(f"  {'total':32s} {sum(v[0] for v in fam.values()):5d} {sum(v[1] for v in fam.values()) / 1e6:8.3f}")
+
+# per kernel instance (name + template arguments + grid) of the last replayed step: launches, total, average
+def short(n):
+    n = re.sub(r"^_ZN2aa\d+", "", n)
+    n = re.sub(r"void aa::", "", n)
+    return n[:70]
+inst = collections.defaultdict(lambda: [0, 0])
+for r in seg:
+    grid = "x".join(str(r.get(k, "")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z") if k in r) or str(r.get("Grid_Size", ""))
+    k = (short(r["Kernel_Name"]), grid)
+    inst[k][0] += 1
+    inst[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+print("last replayed step by kernel instance and grid (launches, total ms, average us):")
+for k, v in sorted(inst.items(), key=lambda kv: -kv[1][1])[:90]:
+    print(f"  {k[0]:70s} grid {k[1]:>16s} {v[0]:4d} {v[1] / 1e6:8.3f} {v[1] / v[0] / 1e3:8.1f}")
