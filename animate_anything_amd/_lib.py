@@ -176,7 +176,7 @@ _host_pointers_ok = False     # only the emulator build (tests/emu) accepts host
 def get() -> C.CDLL:
     global _lib
     if _lib is None:
-        _lib = bind(DEFAULT_PATH)
+        _lib = bind(os.environ.get("AA_LIBRARY") or DEFAULT_PATH)      # AA_LIBRARY: another BUILD of this library (A/B and probe variants of build.py)
     return _lib
 
 

@@ -19,13 +19,15 @@ PROBE_LIB = os.path.join(PKG, "libaa_mi355_probe.so")
 TU_GROUPS = 8             # aa_api_impl.h: tile-table entry i is compiled in unit i % TU_GROUPS
 
 
-def build(force=False, verbose=False, probe=False, ablate=0):
+def build(force=False, verbose=False, probe=False, ablate=0, variant=None):
     """Compile csrc/aa_api.hip + 8 x csrc/aa_tiles.hip -> libaa_mi355.so (skipped when up to date). Returns the path.
     probe=True builds the -DAA_PHASE_PROBE profiling variant (scripts/phase_probe.py) next to it;
     ablate=bits a timing-only -DAA_X_ABLATE variant of the hand-scheduled kernels (scripts/x_ablate.py)."""
     LIB = PROBE_LIB if probe else globals()["LIB"]
     if ablate:
         LIB = os.path.join(PKG, f"libaa_mi355_abl{ablate}.so")
+    if variant:                                             # (name, [-D...]): an A/B build next to the library, loaded through AA_LIBRARY
+        LIB = os.path.join(PKG, f"libaa_mi355_{variant[0]}.so")
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _deps()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -36,6 +38,8 @@ def build(force=False, verbose=False, probe=False, ablate=0):
         flags.insert(0, "-DAA_PHASE_PROBE")
     if ablate:
         flags.insert(0, f"-DAA_X_ABLATE={int(ablate)}")
+    if variant:
+        flags = list(variant[1]) + flags
     if verbose:
         flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
     # one translation unit for the C ABI + TU_GROUPS units with a slice of the contraction tile table each, compiled in parallel
@@ -156,6 +160,11 @@ def audit_x_kernels(lib_path):
     meta = {}
     for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
         meta[m.group(2)] = tuple(int(m.group(k)) for k in (1, 3, 4, 5))
+    # the attention / GroupNorm kernels must not spill either (some wide compiled contraction tiles do - the autotuner never picks them): round 5 first kept the attention scores alive across a test and hipcc spilled 18
+    # registers into the key loop at the kernel's 168-register cap - the 4096-key kernel ran 55 % slower and nothing said so
+    for k, (_agpr, scratch, _vgpr, spills) in sorted(meta.items()):
+        if any(t in k for t in ("attention_kernel", "attention_shortkv_kernel", "groupnorm_")) and (scratch or spills):
+            problems.append(f"{k}: scratch {scratch} bytes, {spills} VGPR spills in a hot kernel")
     xk = {k: v for k, v in meta.items() if "conv_gemm_x_kernel" in k}
     if len(xk) < 16:                                        # 8 tiles x {fp16, bf16} at the very least
         problems.append(f"only {len(xk)} hand-scheduled kernels found")

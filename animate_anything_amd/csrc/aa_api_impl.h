@@ -508,7 +508,15 @@ static int attention_t(const AaAttention& d, void* stream) {
         else                 AA_LAUNCH((attention_small_kernel<T, 80>), grid, dim3(256), lds, stream, d);
         return finish("attention");
     }
-    if (d.q_len > 64) {
+    if (d.q_len >= 128 && d.kv_len > AT_KT && d.kv_len <= ATS_KEYS && !d.causal && !(d._pad & 4)) {
+        // short key sequence, many queries (text cross-attention): K / V fragments resident in registers, each wave walks `qb` 32-query
+        // blocks (AaAttention._pad bit 2 = the general kernel instead: A/B).  qb: enough waves to fill the chip twice over, at most 8 blocks
+        const int n_qb = (d.q_len + 31) / 32;
+        int qb = 8;
+        while (qb > 1 && (int64_t)((n_qb + 4 * qb - 1) / (4 * qb)) * d.heads * nseq < 1024) qb >>= 1;
+        const dim3 grid((n_qb + 4 * qb - 1) / (4 * qb), d.heads, nseq);
+        AA_LAUNCH((attention_shortkv_kernel<T>), grid, dim3(256), 2 * AT_TILE_BYTES, stream, d, qb);
+    } else if (d.q_len > 64) {
         const dim3 grid((d.q_len + 127) / 128, d.heads, nseq);
         AA_LAUNCH((attention_kernel<T, 4>), grid, dim3(256), attn_lds_bytes(d.kv_len), stream, d);
     } else {

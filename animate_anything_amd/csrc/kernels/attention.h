@@ -26,6 +26,9 @@
 
 namespace aa {
 
+#ifndef AA_ATTN_EAGER_MAX
+#define AA_ATTN_EAGER_MAX 0
+#endif
 constexpr int AT_KT = 64;                       // keys per tile
 constexpr float AT_DEFER = 6.0f;                // defer-max threshold, in bits (p stays below 2^6 against a stale maximum)
 constexpr int AT_TILE_BYTES = 2 * AT_KT * 128;  // K tile + V tile of one stage
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
     for (int e = 0; e < 16; ++e) minus_m[e] = 0.0f;
 
     const bool prio = (p._pad & 1) != 0;
-    const bool eager_max = (p._pad & 2) != 0;
+    constexpr bool eager_max = AA_ATTN_EAGER_MAX != 0;
     const int ntiles = (p.kv_len + KT - 1) / KT;
     const bool ragged = (p.kv_len & (KT - 1)) != 0;
     const int stages = attn_stages(p.kv_len);   // 3 (two tiles in flight ahead of the math) or 1 (single tile)
@@ -164,35 +167,38 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
             // S^T - m: the accumulators START at minus the running maximum (zero for the first tile) - the first MFMA of every
             // block takes a register set that holds -m in all 16 entries as its C operand, so no accumulator is initialised per tile
             f32x16 sacc[KB];
-            if (prio) wave_priority<1>();             // (experiment, AaAttention._pad bit 0: matrix clusters above the co-resident waves' softmax)
-            // the two 32-key blocks alternate so that consecutive MFMAs never wait on each other's accumulator
+            auto scores = [&]() __attribute__((always_inline)) {
+                if (prio) wave_priority<1>();         // (experiment, AaAttention._pad bit 0: matrix clusters above the co-resident waves' softmax)
+                // the two 32-key blocks alternate so that consecutive MFMAs never wait on each other's accumulator
 #pragma unroll
-            for (int dk = 0; dk < 4; ++dk)
+                for (int dk = 0; dk < 4; ++dk)
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + kb * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
-                    sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], dk == 0 ? minus_m : sacc[kb]);
+                    for (int kb = 0; kb < KB; ++kb) {
+                        const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + kb * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
+                        sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], dk == 0 ? minus_m : sacc[kb]);
+                    }
+                if (prio) wave_priority<0>();
+                if (p.causal && kt * KT + KT - 1 > q0) {     // causal: keys after the query's own position (tiles that reach past the wave's first query)
+                    const int qpos = q0 + ql;
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int key = kt * KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            if (key > qpos) sacc[kb][e] = -1.0e30f;
+                        }
                 }
-            if (prio) wave_priority<0>();
-            if (p.causal && kt * KT + KT - 1 > q0) {     // causal: keys after the query's own position (tiles that reach past the wave's first query)
-                const int qpos = q0 + ql;
+                if (ragged && kt == ntiles - 1) {           // mask the keys past kv_len (last tile only)
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
+                    for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = kt * KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (key > qpos) sacc[kb][e] = -1.0e30f;
-                    }
-            }
-            if (ragged && kt == ntiles - 1) {           // mask the keys past kv_len (last tile only)
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = kt * KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (key >= p.kv_len) sacc[kb][e] = -1.0e30f;
-                    }
-            }
+                        for (int e = 0; e < 16; ++e) {
+                            const int key = kt * KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            if (key >= p.kv_len) sacc[kb][e] = -1.0e30f;
+                        }
+                }
+            };
+            scores();
             // Row maximum of (score - m) over this tile: three-input maxima (v_max3_f32), independent chains per half block, a tree,
             // one v_permlane32_swap for the other half-wave's keys.  Only the FIRST tile pays for it up front (it centres the
             // softmax on its true row maximum); every later tile exponentiates against the running maximum straight away and looks
@@ -256,25 +262,25 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
                 if constexpr (KB == 2) pst += ps2[2] + ps2[3];
                 return pst[0] + pst[1];
             };
-            if (kt == 0) move_max(row_over(), true);
-            else if (eager_max) {                       // (A/B switch, AaAttention._pad bit 1: the round-2..4 form - every tile computes its maximum)
-                const float over = row_over();
-                if (wave_any(over > AT_DEFER)) move_max(fmaxf(over, 0.0f), false);
-            }
+            if constexpr (eager_max) {                  // (-DAA_ATTN_EAGER_MAX=1 build, A/B only: the round-2..4 form - every tile computes its maximum.  A RUN-time
+                const float over = row_over();          //  switch made hipcc spill 25-37 registers in every instance of this kernel: build.py's audit rejects that)
+                if (kt == 0 || wave_any(over > AT_DEFER)) move_max(kt == 0 ? over : fmaxf(over, 0.0f), kt == 0);
+            } else if (kt == 0) move_max(row_over(), true);
             float psum = exponentiate();
             // Lazy maximum (defer-max, round 5 form): the running maximum has to move only when some p would leave the range the
             // deferral allows (p <= 2^AT_DEFER).  A lane's p's are non-negative, so "one of them exceeds 2^AT_DEFER" implies "their
             // sum does" (and an overflowed p makes the sum inf, a NaN fails the comparison): the sum - needed anyway - is the whole
-            // check.  When it fires the tile's scores, untouched in their registers, are looked at after all; rows that are more than
+            // check.  When it fires the tile is multiplied again and its scores are looked at after all; rows that are more than
             // a bit above their maximum move it (so a flat run of p ~ 2..64 cannot fire tile after tile) and the tile is exponentiated
             // again.  Rare: after the first tile has centred a row, later keys seldom beat it by 6 bits.
             if (kt != 0 && !eager_max && wave_any(!(psum <= 64.0f))) {
                 static_assert(AT_DEFER == 6.0f, "the sum test above is 2^AT_DEFER");
+                // (the scores are NOT kept alive across the test - 32 more live registers at the kernel's 168-register cap spilled
+                //  into the hot loop and cost the 4096-key kernel 55 %, r05e: the rare path multiplies the tile again, K is still in its slot)
+                scores();
                 const float over = row_over();
-                if (wave_any(over > 1.0f)) {
-                    move_max(fmaxf(over, 0.0f), false);
-                    psum = exponentiate();
-                }
+                if (wave_any(over > 1.0f)) move_max(fmaxf(over, 0.0f), false);
+                psum = exponentiate();
             }
             l_run += psum;
             // O^T += V^T P^T: chunk ch = 16 keys; this half-wave's 8 k-slots are keys 16ch + 4h + {0..3} and
@@ -297,6 +303,165 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
         const float l_tot = wave_sum_halves(l_run);
         const float inv = 1.0f / l_tot;
         const int q = q0 + ql;
+        if (q < p.q_len) {
+            T* dst = const_cast<T*>(attn_row<T>(p.o, o, i, p.n_inner, q, head));
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    union { u32x2 raw; T e[4]; } pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk.e[e] = (T)(oacc[db][4 * g + e] * inv);
+                    *reinterpret_cast<u32x2*>(dst + 32 * db + 8 * g + 4 * h) = pk.raw;
+                }
+        }
+    }
+}
+
+
+// ---- Short key sequences, many queries (the text cross-attention: 77 keys against 4096 / 1024 / 256 queries per image) ----------
+// The general kernel above spends a workgroup per 128 queries: K / V staged anew for each, two 64-key tiles (the second holds 13
+// keys), two barriers, an online-softmax rescale - 64.6 us for 178 MB at the 64x64 level (2.8 TB/s), a chain of latencies.  Here
+// the K and V^T fragments of up to 96 keys (3 x 4 + 6 x 2 registers-of-4: 96 registers) are read ONCE per wave from one staged tile
+// pair and STAY in registers while the wave walks `qblocks` 32-query blocks: per block 12 + 12 MFMAs, one single-pass softmax over the
+// lane's 48 scores (every key is present: no running maximum, no rescale), no LDS traffic and no barrier; the next block's Q
+// fragment is fetched while the current one is multiplied.  Same layouts as above (S^T = K Q^T, P^T registers = B operand of
+// O^T = V^T P^T, V^T through ds_read_b64_tr_b16), same operand addressing.  grid = (ceil(q blocks / (4 * qblocks)), heads, sequences).
+constexpr int ATS_KEYS = 96;
+template <typename T>
+__global__ void __launch_bounds__(256, 2) attention_shortkv_kernel(const AaAttention p, const int qblocks) {
+    constexpr int NW = 4, KT = 64, PER = (KT / 4) / NW, TILE_BYTES = 2 * KT * 128;
+    constexpr unsigned OOB = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id();
+    const int h = lane >> 5, ql = lane & 31;
+    const int head = blockIdx.y, seq = blockIdx.z;
+    char* lds = dyn_smem();
+    const int o = seq / p.n_inner, i = seq - o * p.n_inner;
+    const float sl2e = p.scale * 1.4426950408889634f;
+
+    // ---- stage keys 0..127 as two 64-key tiles (layouts of attention_kernel: K rows XOR-swizzled, V in [4 keys][32 d] blocks)
+    const BufRsrc r_k = make_rsrc(p.k.ptr, (unsigned)attn_extent_bytes(p.k, p.n_outer, p.n_inner, p.kv_len));
+    const BufRsrc r_v = make_rsrc(p.v.ptr, (unsigned)attn_extent_bytes(p.v, p.n_outer, p.n_inner, p.kv_len));
+    const unsigned k_seq = (unsigned)((attn_seq_row(p.k, o, i, p.n_inner) * p.k.ld + p.k.col0 + head * 64) * 2);
+    const unsigned v_seq = (unsigned)((attn_seq_row(p.v, o, i, p.n_inner) * p.v.ld + p.v.col0 + head * 64) * 2);
+    const unsigned k_key = (unsigned)(p.k.pos_stride * p.k.ld * 2), v_key = (unsigned)(p.v.pos_stride * p.v.ld * 2);
+    const int kk = lane >> 3;
+    const int vk = 4 * (lane >> 5) + ((lane >> 2) & 3), vd = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        char* sK = lds + t * TILE_BYTES;
+        char* sV = sK + KT * 128;
+#pragma unroll
+        for (int j = 0; j < PER / 2; ++j) {
+            const int n = wave * (PER / 2) + j;
+            const int kl = t * KT + 8 * n + kk, vl = t * KT + 8 * n + vk;
+            async_copy16_buf(r_k, kl < p.kv_len ? k_seq + (unsigned)kl * k_key + (unsigned)(((lane & 7) ^ ((kl >> 1) & 7)) * 16) : OOB, sK + n * 1024);
+            async_copy16_buf(r_v, vl < p.kv_len ? v_seq + (unsigned)vl * v_key + (unsigned)(vd * 2) : OOB, sV + n * 1024);
+        }
+    }
+    // the first Q fragment travels while the keys land
+    const int qb0 = (blockIdx.x * NW + wave) * qblocks;                  // this wave's first 32-query block
+    auto load_q = [&](int qb, u32x4 (&qf)[4]) __attribute__((always_inline)) {
+        const int q = qb * 32 + ql;
+        const bool ok = q < p.q_len;
+        const T* src = attn_row<T>(p.q, o, i, p.n_inner, ok ? q : 0, head) + 8 * h;
+#pragma unroll
+        for (int dk = 0; dk < 4; ++dk) {
+            qf[dk] = u32x4{0u, 0u, 0u, 0u};
+            if (ok) qf[dk] = *reinterpret_cast<const u32x4*>(src + 16 * dk);
+        }
+    };
+    u32x4 q_next[4];
+    load_q(qb0, q_next);
+    dma_wait<0>();
+    block_barrier();
+    // ---- K fragments (A operand of S^T: row = key, 8 consecutive d) and V^T fragments (A operand of O^T) into registers
+    u32x4 kf[3][4], vf[6][2];
+    {
+        const int kf_row = ql * 128, kf_swz = (ql >> 1) & 7;
+        const int vf_off = (2 * h) * 256 + ((lane & 15) >> 2) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int dk = 0; dk < 4; ++dk)
+                kf[kb][dk] = *reinterpret_cast<const u32x4*>(lds + (kb >> 1) * TILE_BYTES + (kb & 1) * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
+#pragma unroll
+        for (int ch = 0; ch < 6; ++ch)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const char* base = lds + (ch >> 2) * TILE_BYTES + KT * 128 + (2 * (ch & 3)) * 1024 + db * 256 + vf_off;
+                const u32x2 lo = lds_read_tr16_b64(base), hi = lds_read_tr16_b64(base + 1024);
+                vf[ch][db] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+    }
+    f32x16 zero16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.0f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (int it = 0; it < qblocks; ++it) {
+        const int qb = qb0 + it;
+        if (qb * 32 >= p.q_len) break;                                   // (wave-uniform)
+        u32x4 qf[4];
+#pragma unroll
+        for (int dk = 0; dk < 4; ++dk) {                                  // scores come out in units of bits: Q * scale * log2(e)
+            Pack8<T> v;
+            v.raw = q_next[dk];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.e[e] = (T)((float)v.e[e] * sl2e);
+            qf[dk] = v.raw;
+        }
+        if (it + 1 < qblocks) load_q(qb + 1, q_next);                     // (rows past q_len load zeros)
+        f32x16 sacc[3];
+#pragma unroll
+        for (int dk = 0; dk < 4; ++dk)
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) sacc[kb] = mfma_32x32x16(T(), kf[kb][dk], qf[dk], dk == 0 ? zero16 : sacc[kb]);
+        if (p.kv_len < ATS_KEYS) {                                       // keys past kv_len (their K rows are zeros: score 0, not -inf)
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (key >= p.kv_len) sacc[kb][e] = -1.0e30f;
+                }
+        }
+        float mx[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const f32x16& a = sacc[c >> 1];
+            const int b = 8 * (c & 1);
+            const float m0 = fmaxf(fmaxf(a[b], a[b + 1]), a[b + 2]);
+            const float m1 = fmaxf(fmaxf(a[b + 3], a[b + 4]), a[b + 5]);
+            mx[c] = fmaxf(fmaxf(m0, m1), fmaxf(a[b + 6], a[b + 7]));
+        }
+        const float m = wave_max_halves(fmaxf(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])), fmaxf(mx[4], mx[5])));
+        f32x2 ps = f32x2{0.0f, 0.0f};
+        u32x4 pf[6];
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                Pack8<T> pk;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    f32x2 pe;
+                    pe[0] = fast_exp2(sacc[kb][8 * c + e] - m);
+                    pe[1] = fast_exp2(sacc[kb][8 * c + e + 1] - m);
+                    ps += pe;
+                    pk.e[e] = (T)pe[0];
+                    pk.e[e + 1] = (T)pe[1];
+                }
+                pf[2 * kb + c] = pk.raw;
+            }
+        const float l_tot = wave_sum_halves(ps[0] + ps[1]);
+        f32x16 oacc[2];
+#pragma unroll
+        for (int ch = 0; ch < 6; ++ch)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) oacc[db] = mfma_32x32x16(T(), vf[ch][db], pf[ch], ch == 0 ? zero16 : oacc[db]);
+        const float inv = 1.0f / l_tot;
+        const int q = qb * 32 + ql;
         if (q < p.q_len) {
             T* dst = const_cast<T*>(attn_row<T>(p.o, o, i, p.n_inner, q, head));
 #pragma unroll

@@ -243,6 +243,7 @@ class UNet3DConditionModel(nn.Module):
         a captured graph cannot)."""
         self._temb_pack = None
         self._text_pack = None
+        self._co_pack = None
         if getattr(self, "_graph", None) is not None:
             self._graph = {}
 
@@ -370,7 +371,25 @@ class UNet3DConditionModel(nn.Module):
         for i, blk in enumerate(self.up_blocks):
             x, g = blk.tokens(x, g, skips, temb_silu, text_tokens, text_len, upsample_size=upsample_sizes[i])
         x = self.conv_norm_out.tokens(x, g.images, g.hw, silu=True)
-        return self.conv_out.tokens(x, ops.conv3x3_geom(g.images, g.h, g.w))
+        return ops.conv_gemm(x, self._conv_out_pack(), ops.conv3x3_geom(g.images, g.h, g.w))
+
+    def _conv_out_pack(self):
+        """conv_out (320 -> 4 channels, 3x3) with zero filters appended up to 8 output channels: 16-byte output rows are what the
+        LDS-DMA contraction kernels store, so the head leaves the generic gather kernel (156 us at 20 TF/s at the 64x64 level,
+        the slowest launch of a step per FLOP) for the tiled path; consumers read the first `out_channels` columns of the
+        [tokens, 8] result (the solver kernel takes the row pitch, `forward` slices)."""
+        from .layers import weights_key
+        w, b = self.conv_out.weight, self.conv_out.bias
+        n = w.shape[0]
+        if n % 8 == 0 or w.shape[1] % 64:
+            return self.conv_out.packed()
+        key = weights_key(w, b)
+        if getattr(self, "_co_pack", None) is None or self._co_key != key:
+            pad = (-n) % 8
+            wp = torch.cat([w.detach(), torch.zeros((pad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)])
+            bp = None if b is None else torch.cat([b.detach(), torch.zeros(pad, dtype=b.dtype, device=b.device)])
+            self._co_pack, self._co_key = ops.pack_weight(wp, bp), key
+        return self._co_pack
 
     def forward(self, sample, timestep, encoder_hidden_states, condition_latent, mask, class_labels=None,
                 timestep_cond=None, attention_mask=None, cross_attention_kwargs=None,
@@ -402,7 +421,7 @@ class UNet3DConditionModel(nn.Module):
         sess.load(sample=sample, cond=condition_latent, mask=mask if use_mask else None, t=t, motion=motion_t,
                   cond_emb=cond_emb, text=encoder_hidden_states)
         y = sess.run()
-        y = y.reshape(b, frames + 1, h, w, -1).permute(0, 4, 1, 2, 3)[:, :, 1:]       # :521-522
+        y = y.reshape(b, frames + 1, h, w, -1)[..., :self.conv_out.out_channels].permute(0, 4, 1, 2, 3)[:, :, 1:]       # :521-522 (columns past out_channels: _conv_out_pack)
         return UNet3DConditionOutput(sample=y) if return_dict else (y,)
 
     # ------------------------------------------------------------------ sessions: static inputs (+ hipGraph replay)

@@ -322,6 +322,32 @@ def test_attention_cross_text(backend):
     close(o, ref, tol=1e-2)
 
 
+@pytest.mark.parametrize("L,Lt,heads,frames", [(300, 77, 2, 2), (129, 96, 1, 1), (1000, 65, 1, 3), (256, 77, 5, 1)])
+def test_attention_short_key_sequences(backend, L, Lt, heads, frames):
+    """Round 5: 65..96 keys against >= 128 queries (the text cross-attention of the UNets, oracle/layers.py:150-189 with 77 CLIP
+    tokens) runs attention_shortkv_kernel - K / V^T fragments resident in registers, every wave walks several 32-query blocks, one
+    single-pass softmax per block.  Against fp32 SDPA and against the general kernel (AaAttention._pad bit 2), with ragged query
+    tails (L % 32 != 0, L % 128 != 0), the per-clip text layout (kv_outer_div = frames) and every key count edge (65, 77, 96)."""
+    clips = 2
+    C = heads * 64
+    q = rnd(clips * frames * L, C, seed=161)
+    kv = rnd(clips * Lt, 2 * C, scale=1.5, seed=162)
+    run = lambda: ops.attention(q, 0, kv, 0, kv, C, heads, clips * frames, 1, L, Lt, (L, 0, 1), (Lt, 0, 1), kv_outer_div=frames)
+    o = run()
+    keep = ops.ATTN_FLAGS
+    ops.ATTN_FLAGS = keep | 4
+    try:
+        o_general = run()
+    finally:
+        ops.ATTN_FLAGS = keep
+    qq = q.reshape(clips, frames, L, heads, 64).permute(0, 1, 3, 2, 4)
+    kk = kv.reshape(clips, 1, Lt, 2, heads, 64).permute(3, 0, 1, 4, 2, 5)
+    ref = sdpa(qq, kk[0], kk[1]).permute(0, 1, 3, 2, 4).reshape(-1, C)
+    assert torch.isfinite(o.float()).all()
+    close(o, ref, tol=1e-2)
+    close(o, o_general.float(), tol=5e-3)
+
+
 def test_attention_temporal(backend):
     clips, frames, hw, heads = 2, 5, 6, 2
     C = heads * 64
