@@ -5,12 +5,12 @@ TAG=${1:-stepsq}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-other-form --tile-cache $OUT/tile_cache.json > $OUT/prep.log 2>&1
+python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-other-form --no-vae --tile-cache $OUT/tile_cache.json > $OUT/prep.log 2>&1
 cd /tmp
 run() {
   name=$1; shift
   timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-other-form --tile-cache $OUT/tile_cache.json > $OUT/$name.log 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-other-form --no-vae --tile-cache $OUT/tile_cache.json > $OUT/$name.log 2>&1
   echo "$name rc=$?" >> $OUT/summary.log
 }
 run sq1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE
