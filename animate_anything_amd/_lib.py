@@ -30,6 +30,7 @@ class AaConvGemm(C.Structure):
         ("out_sy", C.c_int32), ("out_sx", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_cols", C.c_void_p), ("ln_parts", C.c_int32), ("ln_eps", C.c_float),
         ("row_stats", C.c_void_p), ("row_stats_parts", C.c_int32), ("tickets_len", C.c_int32), ("tickets", C.c_void_p),
+        ("row_coef", C.c_void_p), ("row_coef_eps", C.c_float), ("_reserved107", C.c_int32),
     ]
 
 
@@ -109,7 +110,7 @@ class AaEulerStepTok(C.Structure):
     ]
 
 
-SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_conv_gemm_row_stats_parts", "aa_conv_gemm_tickets", "aa_conv_gemm_reduce_launches", "aa_conv_gemm_tile_flags", "aa_ln_finalize", "aa_groupnorm_workspace", "aa_groupnorm", "aa_set_groupnorm_two_pass", "aa_groupnorm_plan",
+SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_conv_gemm_row_stats_parts", "aa_conv_gemm_row_coef_ok", "aa_conv_gemm_tickets", "aa_conv_gemm_reduce_launches", "aa_conv_gemm_tile_flags", "aa_ln_finalize", "aa_groupnorm_workspace", "aa_groupnorm", "aa_set_groupnorm_two_pass", "aa_groupnorm_plan",
            "aa_layernorm", "aa_attention", "aa_softmax_rows", "aa_cfg_dpm_step",
            "aa_timestep_embedding", "aa_pack_latents", "aa_cfg_dpm_step_tokens",
            "aa_blend", "aa_pack_frames", "aa_cfg_euler_step_tokens")
@@ -139,6 +140,8 @@ def bind(path: str) -> C.CDLL:
     lib.aa_ln_finalize.restype = C.c_int
     lib.aa_conv_gemm_row_stats_parts.argtypes = [C.POINTER(AaConvGemm)]
     lib.aa_conv_gemm_row_stats_parts.restype = C.c_int
+    lib.aa_conv_gemm_row_coef_ok.argtypes = [C.POINTER(AaConvGemm)]
+    lib.aa_conv_gemm_row_coef_ok.restype = C.c_int
     lib.aa_conv_gemm_launch_count.argtypes = [C.POINTER(AaConvGemm)]
     lib.aa_conv_gemm_tickets.argtypes = [C.POINTER(AaConvGemm)]
     lib.aa_conv_gemm_reduce_launches.argtypes = [C.POINTER(AaConvGemm)]

@@ -575,6 +575,22 @@ int aa_conv_gemm_row_stats_parts(const AaConvGemm* d) {
     return (d->n_pad / c.bn) * c.wn;
 }
 
+int aa_conv_gemm_row_coef_ok(const AaConvGemm* d) {
+    using namespace aa;
+    if (!d || !cg_dma_ok(*d)) return 0;
+    AaConvGemm q = *d;                                   // asked as a plain statistics call
+    q.row_coef = nullptr;
+    const int parts = aa_conv_gemm_row_stats_parts(&q);
+    if (parts <= 0) return 0;
+    const int M = (int)((int64_t)d->n_img * d->h_out * d->w_out);
+    CgPlan pl = cg_plan(q, M, q.workspace != nullptr);
+    if (pl.workspace > (size_t)q.workspace_bytes) pl = cg_plan(q, M, false);
+    const CgCfg& c = kCgCfgs[pl.cfg];
+    // one launch, one column tile: the tile's waves hold the whole row between them; the plain K loop only (a K split that finishes in
+    // the kernel runs its epilogue in ONE of the tile's workgroups: the others never reach the exchange barrier - and it is not needed here)
+    return (d->n_pad == c.bn && parts == c.wn && pl.splits == 1 && pl.m_main >= M && c.wm * c.wn * (c.bm / c.wm) * 8 <= CGX_COEF_BYTES) ? 1 : 0;
+}
+
 static bool cg_plan_of(const AaConvGemm* d, aa::CgPlan& pl, int& M) {
     using namespace aa;
     if (!d || !cg_dma_ok(*d)) return false;
@@ -645,6 +661,11 @@ int aa_conv_gemm(const AaConvGemm* d, void* stream) {
             return fail(AA_E_SHAPE, "conv_gemm: the LayerNorm fold (ln_stats) is a plain or GEGLU linear call: ln_cols, no bias / row vector / residual / activation / scales");
         if (d->ln_parts < 0 || d->ln_parts > 64 || (d->ln_parts > 0 && !(d->ln_eps > 0.0f)))
             return fail(AA_E_SHAPE, "conv_gemm: ln_parts=%d (0: finalised coefficients, 1..64: raw partial sums + ln_eps > 0)", d->ln_parts);
+    }
+    if (d->row_coef) {
+        if (d->row_stats || d->row_stats_parts || !(d->row_coef_eps > 0.0f) || !aligned16(d->row_coef) || !aa_conv_gemm_row_coef_ok(d))
+            return fail(AA_E_SHAPE, "conv_gemm: row_coef needs a statistics-emitting call whose tile spans the output row (aa_conv_gemm_row_coef_ok), "
+                                    "row_stats NULL, row_coef_eps > 0, 16-byte aligned coefficients");
     }
     if (d->row_stats && d->row_stats_parts != aa_conv_gemm_row_stats_parts(d))
         return fail(AA_E_SHAPE, "conv_gemm: row_stats_parts=%d, this call emits %d partial statistics per row (aa_conv_gemm_row_stats_parts)", d->row_stats_parts, aa_conv_gemm_row_stats_parts(d));

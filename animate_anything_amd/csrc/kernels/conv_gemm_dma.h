@@ -92,8 +92,12 @@ __device__ __forceinline__ LnRow cgd_ln_row(const AaConvGemm& p, const int m) {
     return LnRow{c[2], c[0] * c[2], c[0], c[1]};
 }
 
+// sCoef (STATS with AaConvGemm.row_coef, version 107): LDS scratch [waves][MI * 32][2] fp32 of a workgroup whose tile spans the output row, WN_ its
+// waves per tile row: the waves park their partial (sum, sum of squares) there, meet at a barrier, and the first wave of every tile row adds them in
+// wave order and stores the finished coefficients - the arithmetic and order of ln_finalize_kernel (norm.h), one launch fewer per LayerNorm.
 template <typename T, int MI, int NI, bool GEGLU, bool RV, bool POST, bool BIAS, bool LNF, bool STATS, typename Get>
-__device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW, const int part, const LnRstd<MI> ln_rstd) {
+__device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW, const int part, const LnRstd<MI> ln_rstd,
+                                                  float* sCoef = nullptr, const int WN_ = 1) {
     // ln_rstd (LNF): rstd of this lane's row of every block row, still in the caller's registers from its accumulator start
     static_assert(!GEGLU || (NI % 2 == 0 && !RV && !POST), "GEGLU pairs value block j with gate block j + 1");
     static_assert(!LNF || (!RV && !POST && !BIAS && !STATS), "the LayerNorm fold covers the plain and the GEGLU form");
@@ -243,13 +247,41 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
         if constexpr (STATS) {
             const float row_sum = wave_sum_halves(st_sum), row_sq = wave_sum_halves(st_sq);      // the other 16 columns of every block
             const int m = m_wave + (int)row;
-            if (eh == 0 && m < M) {
+            if (sCoef != nullptr) {                      // (the whole workgroup takes this branch or none: p.row_coef)
+                if (eh == 0) {
+                    float* dst = sCoef + ((int)(threadIdx.x >> 6) * (MI * 32) + (int)row) * 2;
+                    dst[0] = row_sum;
+                    dst[1] = row_sq;
+                }
+            } else if (eh == 0 && m < M) {
                 float* dst = p.row_stats + ((int64_t)m * p.row_stats_parts + part) * 2;
                 dst[0] = row_sum;
                 dst[1] = row_sq;
             }
         }
     });
+    if constexpr (STATS) {
+        if (sCoef != nullptr) {
+            __syncthreads();                             // every wave of the tile has parked its partial sums
+            const int wave = (int)(threadIdx.x >> 6);
+            if (wave % WN_ == 0 && eh == 0) {            // first wave of a tile row: its rows, the partials of waves wave .. wave + WN_ - 1 in order
+                const float inv_c = 1.0f / (float)p.n_out;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int r = i * 32 + ec, m = m_wave + r;
+                    float s_ = 0.0f, q_ = 0.0f;
+                    for (int t = 0; t < WN_; ++t) {
+                        const float* src = sCoef + ((wave + t) * (MI * 32) + r) * 2;
+                        s_ += src[0]; q_ += src[1];
+                    }
+                    const float mean = s_ * inv_c;
+                    const float var = fmaxf(q_ * inv_c - mean * mean, 0.0f);
+                    const float sd = sqrtf(var + p.row_coef_eps);
+                    if (m < M) *reinterpret_cast<f32x4*>(p.row_coef + (int64_t)m * 4) = f32x4{-mean, sd, 1.0f / sd, 0.0f};
+                }
+            }
+        }
+    }
 }
 
 // BIAS_FOLDED: the accumulators were started from the bias (conv_gemm_x.h) and sBiasW holds zeros.
@@ -257,7 +289,7 @@ __device__ __forceinline__ void cgd_epilogue_fast(const AaConvGemm& p, const int
 // accumulators from the rank-1 terms of a folded LayerNorm (AaConvGemm.ln_stats): its epilogue form only scales by rstd.
 template <typename T, int MI, int NI, bool BIAS_FOLDED = false, typename Get>
 __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M, Get&& get, const int m_wave, const int n_wave, const T* sBiasW,
-                                               const int part = -1, const LnRstd<MI> ln_rstd = LnRstd<MI>{{}, false}) {
+                                               const int part = -1, const LnRstd<MI> ln_rstd = LnRstd<MI>{{}, false}, float* sCoef = nullptr, const int WN_ = 1) {
     // get(IntTag<i>, IntTag<j>) -> the 16 accumulators of 32x32 block (i, j) of this lane (an array element, or a read-out
     // of the literal accumulation registers of conv_gemm_x.h)
     const int lane = threadIdx.x & 63;
@@ -272,7 +304,9 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
     const bool silu = p.act == AA_ACT_SILU;
     const bool pre_is_rv = rowvec != nullptr;             // the prefetch registers carry the row vector, else the residual
     const bool lnf = p.ln_stats != nullptr;               // LayerNorm folded into this contraction (host: no bias / row vector / residual with it)
-    const bool stats = p.row_stats != nullptr && part >= 0;
+    const bool coef = p.row_coef != nullptr && part >= 0 && sCoef != nullptr;      // (host: only where the tile spans the row - aa_conv_gemm_row_coef_ok)
+    const bool stats = (p.row_stats != nullptr || coef) && part >= 0;
+    float* const sC = coef ? sCoef : nullptr;
     // the combinations that carry the step take the branch-free forms - where the accumulators sit in the accumulation registers
     // (conv_gemm_x.h): next to 128-160 accumulators in VGPRs the extra offsets spill (measured: 160-220 dwords of scratch)
     // (a folded LayerNorm takes its rstd-only form only where THIS kernel instance started its accumulators from the fold's rank-1
@@ -289,8 +323,8 @@ __device__ __forceinline__ void cgd_epilogue_g(const AaConvGemm& p, const int M,
             else cgd_epilogue_fast<T, MI, NI, false, true, false, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd);
             return;
         } else if (stats) {
-            if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED, false, true>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd);
-            else cgd_epilogue_fast<T, MI, NI, false, false, false, !BIAS_FOLDED, false, true>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd);
+            if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED, false, true>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd, sC, WN_);
+            else cgd_epilogue_fast<T, MI, NI, false, false, false, !BIAS_FOLDED, false, true>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd, sC, WN_);
             return;
         } else {
             if (post) cgd_epilogue_fast<T, MI, NI, false, false, true, !BIAS_FOLDED, false, false>(p, M, get, m_wave, n_wave, sBiasW, part, ln_rstd);

@@ -27,8 +27,14 @@ namespace aa {
 // the tiles that can start their accumulators from a folded LayerNorm (one wave per SIMD, K step 64) keep a private copy of the two
 // column vectors of each wave's columns behind the bias slice: [wave][2][256] fp32 (an LDS-DMA piece deposits 1 KiB)
 __host__ __device__ constexpr bool cgx_ln_ok(int bk, int wm, int wn, int per_cu) { return wm * wn * per_cu <= 4 && bk == 64; }
-__host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring, int wm, int wn, int per_cu) {
+// + 4 KiB behind everything else: where the waves of a row-spanning tile exchange their row statistics (AaConvGemm.row_coef, version 107:
+// [waves][rows of a wave][2] fp32 - 4 x 128 or 8 x 64 rows)
+constexpr int CGX_COEF_BYTES = 4096;
+__host__ __device__ inline int cgx_lds_main_bytes(int bm, int bn, int bk, int ring, int wm, int wn, int per_cu) {
     return cgd_lds_bytes(bm, bn, bk, ring) + (cgx_ln_ok(bk, wm, wn, per_cu) ? wm * wn * 2048 : 0);
+}
+__host__ __device__ inline int cgx_lds_bytes(int bm, int bn, int bk, int ring, int wm, int wn, int per_cu) {
+    return cgx_lds_main_bytes(bm, bn, bk, ring, wm, wn, per_cu) + CGX_COEF_BYTES;
 }
 
 // Tiles whose K-split launches can finish inside the kernel (AaConvGemm.tickets): the ones the small-M levels split along K - 128 x 128
@@ -563,9 +569,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
         return;
         }
     }
+    static_assert(NW * (BM / WM) * 8 <= CGX_COEF_BYTES, "row-statistics exchange area");
+    float* sCoef = reinterpret_cast<float*>(smem + cgx_lds_main_bytes(BM, BN, BK, RING, WM, WN, PER_CU));
     cgd_epilogue_g<T, MI, NI, true>(p, M, [&](auto i_, auto j_) __attribute__((always_inline)) { return acc_get<decltype(i_)::value * NI + decltype(j_)::value>(af); },
                               m_tile + wm * (BM / WM), n_wave, sBias + wn * (BN / WN),
-                              p.row_stats ? tile_n * WN + wn : -1, ln_scale);
+                              (p.row_stats || p.row_coef) ? tile_n * WN + wn : -1, ln_scale, (p.row_coef && tiles_n == 1) ? sCoef : nullptr, WN);
     stamp(5);
     stamp_wall(4, -1);
 }

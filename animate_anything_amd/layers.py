@@ -426,9 +426,9 @@ class BasicTransformerBlock(nn.Module):
         tiles) leaves None and that LayerNorm runs as a kernel."""
         fold = LN_FOLD
         if fold and x_stats is not None:
-            x, st = self.attn1.self_tokens(x, x, g, temporal, ln=(self.norm1, x_stats), row_stats=True)
+            x, st = self.attn1.self_tokens(x, x, g, temporal, ln=(self.norm1, x_stats), row_stats=True, coef_eps=self.norm2.eps)
         else:
-            x, st = self.attn1.self_tokens(self.norm1.tokens(x), x, g, temporal, row_stats=True) if fold else \
+            x, st = self.attn1.self_tokens(self.norm1.tokens(x), x, g, temporal, row_stats=True, coef_eps=self.norm2.eps) if fold else \
                     (self.attn1.self_tokens(self.norm1.tokens(x), x, g, temporal), None)
         if dup > 1:
             x = torch.cat([x] * dup)
@@ -439,9 +439,9 @@ class BasicTransformerBlock(nn.Module):
         fold_ff = fold and LN_FOLD_FF
         if self.attn2.is_cross:
             kv = self.attn2.text_kv(text)
-            r = self.attn2.cross_tokens(xin, x, g, kv, text_len, ln=ln2, row_stats=fold_ff)
+            r = self.attn2.cross_tokens(xin, x, g, kv, text_len, ln=ln2, row_stats=fold_ff, coef_eps=self.norm3.eps)
         else:
-            r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, row_stats=fold_ff)
+            r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, row_stats=fold_ff, coef_eps=self.norm3.eps)
         x, st = r if fold_ff else (r, None)
         if st is not None:
             return self.ff.tokens(x, residual=x, ln=(self.norm3, st), tail=tail)
@@ -487,7 +487,7 @@ class Transformer2DModel(_MergedTail, nn.Module):
 
     def tokens(self, x, g: Grid, text, text_len, dup: int = 1):
         """`dup` > 1 (see BasicTransformerBlock.tokens): x / g are the single copy, the result covers all `dup` groups."""
-        h, st = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw), row_stats=True) if LN_FOLD else \
+        h, st = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw), row_stats=True, coef_eps=self.transformer_blocks[0].norm1.eps) if LN_FOLD else \
                 (self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw)), None)
         outer = torch.cat([x] * dup) if dup > 1 else x
         mt, last = self.merged_tail(), len(self.transformer_blocks) - 1
@@ -513,7 +513,7 @@ class TransformerTemporalModel(_MergedTail, nn.Module):
         self.proj_out = Linear(inner, in_channels)
 
     def tokens(self, x, g: Grid):
-        h, st = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw), row_stats=True) if LN_FOLD else \
+        h, st = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw), row_stats=True, coef_eps=self.transformer_blocks[0].norm1.eps) if LN_FOLD else \
                 (self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw)), None)
         mt, last = self.merged_tail(), len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):

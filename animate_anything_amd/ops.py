@@ -39,6 +39,7 @@ ATTN_FLAGS = int(os.environ.get("AA_ATTN_FLAGS", "0"))   # experiments: AaAttent
 # sums sit in every tile's prologue) - the launch stays the default.
 LN_FINALIZE_LAUNCH = os.environ.get("AA_LN_RAW", "0") != "1"
 TILE_PICKER = None    # tests / scripts/debug: callable(signature key, [(tile, K splits), ...]) -> the pair a conv_gemm call runs with (GPU or emulator)
+PRODUCER_COEF = os.environ.get("AA_PRODUCER_COEF", "1") == "1"   # ABI 107: a producer whose tile spans the row writes the LayerNorm coefficients itself (no aa_ln_finalize launch)
 LN_RAW_ANY_PARTS = False     # tests: let the consumer finalise any number of partial sums per row (a chain of dependent loads: +12-23 %)
 K_SPLITS = 0          # tests: explicit K split count for calls that are not autotuned (0 = library decides)
 # K-split launches of the hand-scheduled tiles can finish inside the kernel (AaConvGemm.tickets, ABI 106).  Measured on the step (r04g):
@@ -436,7 +437,7 @@ class RowStats:
     """Partial (sum, sum of squares) per row of a token matrix, [rows, parts, 2] fp32, left by the contraction that wrote it
     (AaConvGemm.row_stats); `coef(channels, eps)` turns them (aa_ln_finalize, once) into the per-row (-mean, sqrt(var + eps),
     rstd, 0) that the contraction folding the LayerNorm of that matrix takes (AaConvGemm.ln_stats)."""
-    data: torch.Tensor
+    data: Optional[torch.Tensor]      # None: the producer wrote the finished coefficients itself (AaConvGemm.row_coef, ABI 107)
     rows: int
     parts: int
     _coef: Optional[torch.Tensor] = None
@@ -444,12 +445,16 @@ class RowStats:
 
     def coef(self, channels, eps):
         if self._coef is None or self._coef_key != (channels, eps):
+            if self.data is None:
+                raise RuntimeError("RowStats: finished coefficients for (channels, eps) = %r were asked for %r" % (self._coef_key, (channels, eps)))
             out = torch.empty(self.rows, 4, dtype=torch.float32, device=self.data.device)
             _run(_lib.get().aa_ln_finalize, _ptr(self.data), self.parts, _ptr(out), self.rows, channels, float(eps), _stream(self.data))
             self._coef, self._coef_key = out, (channels, eps)
         return self._coef
 
     def repeat(self, n):
+        if self.data is None:
+            return RowStats(None, self.rows * n, 0, torch.cat([self._coef] * n), self._coef_key)
         return RowStats(torch.cat([self.data] * n), self.rows * n, self.parts)
 
 
@@ -500,11 +505,14 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
               rowvec: Optional[torch.Tensor] = None, rowvec_div: int = 1,
               residual: Optional[torch.Tensor] = None, act: int = AA_ACT_NONE, out_dtype=None,
               out_scale: float = 1.0, bias_per_row: bool = False, out: Optional[torch.Tensor] = None,
-              bias: Optional[torch.Tensor] = "packed", acc_scale: float = 1.0, out_map=None, ln_stats=None, row_stats: bool = False):
+              bias: Optional[torch.Tensor] = "packed", acc_scale: float = 1.0, out_map=None, ln_stats=None, row_stats: bool = False,
+              coef_eps: Optional[float] = None):
     """`out_map` = (sy, sx, oy, ox): GEMM row (img, y, x) goes to pixel (y * sy + oy, x * sx + ox) of the [n_img, h_out * sy,
     w_out * sx] grid that `out` (required then) holds - AaConvGemm.out_sy .. out_ox.
     `ln_stats` = RowStats of x0's rows (from the call that produced x0): `pw` must carry a folded LayerNorm (pack_weight(ln=...)).
-    `row_stats=True`: returns (out, RowStats or None) - the partial row statistics of `out` when this call can emit them."""
+    `row_stats=True`: returns (out, RowStats or None) - the partial row statistics of `out` when this call can emit them; with
+    `coef_eps` (the epsilon of the LayerNorm that will consume them) a call whose tile spans the output row writes the finished
+    per-row coefficients itself (ABI 107: no aa_ln_finalize launch in front of the consumer)."""
     lib = _lib.get()
     osc = 1 if out_map is None else out_map[0] * out_map[1]
     if out_map is not None and (out is None or out.shape[0] != g.rows * osc):
@@ -569,7 +577,7 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     if ln_stats is not None:
         if pw.ln_cols is None or ln_stats.rows != g.rows:
             raise RuntimeError("conv_gemm: ln_stats needs weights packed with a folded LayerNorm and statistics of every row of x0")
-        if LN_FINALIZE_LAUNCH or (ln_stats.parts not in (2, 10) and not LN_RAW_ANY_PARTS):      # aa_ln_finalize in between (r04h: finalising the pieces of a row one dependent load
+        if ln_stats.data is None or LN_FINALIZE_LAUNCH or (ln_stats.parts not in (2, 10) and not LN_RAW_ANY_PARTS):      # aa_ln_finalize in between (r04h: finalising the pieces of a row one dependent load
                                                                                       # after the other costs the consumer 12-23 %: unrolled forms for 2 / 10 parts only)
             d.ln_stats, d.ln_cols = _ptr(ln_stats.coef(c0, pw.ln_eps)), _ptr(pw.ln_cols)
         else:                                             # the kernel finalises the producer's partial sums itself
@@ -613,7 +621,11 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
     stats = None
     if row_stats:                                         # after tile / workspace are settled: the plan decides whether it can emit them
         parts = lib.aa_conv_gemm_row_stats_parts(C.byref(d))
-        if parts > 0:
+        if parts > 0 and coef_eps is not None and PRODUCER_COEF and lib.aa_conv_gemm_row_coef_ok(C.byref(d)):
+            coef = torch.empty(g.rows, 4, dtype=torch.float32, device=x0.device)       # the tile spans the row: finished coefficients
+            stats = RowStats(None, g.rows, 0, coef, (pw.n_out, float(coef_eps)))
+            d.row_coef, d.row_coef_eps = _ptr(coef), float(coef_eps)
+        elif parts > 0:
             stats = RowStats(torch.empty(g.rows, parts, 2, dtype=torch.float32, device=x0.device), g.rows, parts)
             d.row_stats, d.row_stats_parts = _ptr(stats.data), parts
     _run(lib.aa_conv_gemm, C.byref(d), _stream(x0))

@@ -154,7 +154,10 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
     # ONE definition: contraction-kernel launches and split-K reduce launches are counted apart; `avg_kernel_launch_us`
     # and the PMC bytes per launch refer to the contraction kernels only
     reduces = sum(int(lib.aa_conv_gemm_reduce_launches(C.byref(d))) for d, _ in trace)
-    launches = sum(int(lib.aa_conv_gemm_launch_count(C.byref(d))) for d, _ in trace) - reduces
+    # calls the LDS-DMA family cannot carry (channels not a multiple of 64, output rows not 16-byte pieces: conv_in2) run the generic gather
+    # kernel - one launch each, counted apart: `launches` is what the PMC / rocprof records list under the contraction family
+    generic = sum(1 for d, _ in trace if (d.c0 + d.c1) % 64 or d.c0 % 64 or (d.n_out // 2 if d.geglu else d.n_out) % 8 or d.out_dtype != d.dtype)
+    launches = sum(int(lib.aa_conv_gemm_launch_count(C.byref(d))) for d, _ in trace) - reduces - generic
     alg_bytes = 0.0
     for d, _ in trace:
         m = d.n_img * d.h_out * d.w_out
@@ -221,7 +224,8 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
                             else f"null: no PMC measurement of this library ({stale or 'no profiles/r*_traffic_pmc.json'}); run scripts/pmc_traffic.sh",
             "library_sha256_16": library_id(),
             "kernel": "contraction kernels: aa::conv_gemm_dma_kernel / conv3x3_slab_kernel / conv_gemm_x_kernel (LDS-DMA implicit-GEMM conv / linear), all instances",
-            "contraction_launches_per_step": launches, "reduce_launches_per_step": reduces, "aa_conv_gemm_calls_per_step": len(trace),
+            "contraction_launches_per_step": launches, "reduce_launches_per_step": reduces, "generic_kernel_launches_per_step": generic,
+            "aa_conv_gemm_calls_per_step": len(trace),
             "avg_kernel_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
             "flop_per_step_in_kernel": flops, "kernel_ms_per_step": round(gemm_ms, 3),
             "algorithmic_bytes_per_step": round(alg_bytes), "traffic_bytes_per_step": traffic_step,

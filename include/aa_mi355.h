@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AA_VERSION 106
+#define AA_VERSION 107
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
@@ -125,6 +125,14 @@ typedef struct AaConvGemm {
      * and runs the usual epilogue.  NULL: partials + splitk reduce launch as before. */
     int32_t tickets_len;
     int32_t* tickets;
+    /* version 107: a producer whose tile spans the whole output row (one column tile: aa_conv_gemm_row_coef_ok(d) == 1) finishes the row
+     * statistics itself - its waves exchange their partial sums through LDS behind the epilogue - and writes the per-row coefficients
+     * [M][4] fp32 (-mean, sqrt(var + eps), rstd, 0) that aa_ln_finalize would have produced from `row_stats` (same arithmetic, same
+     * summation order): the consuming call takes them as `ln_stats` with ln_parts == 0 and no launch sits in between.  With `row_coef`
+     * set, `row_stats` must be NULL (row_stats_parts 0); the row width is n_out. */
+    float* row_coef;
+    float row_coef_eps;     /* the consuming LayerNorm's epsilon (> 0) */
+    int32_t _reserved107;
 } AaConvGemm;
 
 /* Bytes of fp32 scratch with which aa_conv_gemm would split the K loop of this call over several workgroups
@@ -144,6 +152,10 @@ int aa_conv_gemm_reduce_launches(const AaConvGemm* d);
  * 0 when the way it carries the call out cannot emit them (compiled tiles, K splits, a split-off last round) - the caller then runs
  * the LayerNorm it wanted to fold as a kernel. */
 int aa_conv_gemm_row_stats_parts(const AaConvGemm* d);
+/* 1 iff this call (with `row_coef` in place of `row_stats`) would write finished row coefficients (version 107): a call that can emit row
+ * statistics at all, carried out by a tile as wide as the packed output (one column tile).  Answered for the descriptor as it stands
+ * (tile, k_splits, workspace), like aa_conv_gemm_row_stats_parts. */
+int aa_conv_gemm_row_coef_ok(const AaConvGemm* d);
 /* Between the two (version 105): stats [rows][parts][2] fp32 partial (sum, sum of squares) over `channels` values per row ->
  * coef [rows][4] fp32 = (-mean, sqrt(var + eps), rstd, 0), the `ln_stats` operand of the consuming aa_conv_gemm
  * (torch.nn.LayerNorm statistics: biased variance; reference use: diffusers BasicTransformerBlock.norm1 / norm2 / norm3). */

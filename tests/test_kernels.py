@@ -504,6 +504,49 @@ def test_layernorm_folded_into_the_consuming_contraction(backend, M, C, ptile, c
         ops.conv_gemm(y, pw, ops.linear_geom(M))                      # folded weights without statistics
 
 
+@pytest.mark.parametrize("M,C,ptile,ctile,geglu", [(300, 320, 49, 39, False), (500, 320, 39, 36, True), (520, 256, 36, 38, True), (300, 256, 46, 1, False),
+                                                 (200, 128, 47, 0, False), (300, 256, 40, 3, True), (700, 320, 37, 49, False)])
+def test_layernorm_coefficients_from_the_producer(backend, M, C, ptile, ctile, geglu):
+    """ABI 107 (AaConvGemm.row_coef): a producer whose tile spans the output row (one column tile: 320 channels on a 320-column tile,
+    256 on a 256-column one, 128 on 128) lets its waves exchange their partial row sums through LDS behind the epilogue and writes the
+    per-row coefficients (-mean, sqrt(var + eps), rstd, 0) itself - what aa_ln_finalize computes from the partial sums, to the last bit
+    (same arithmetic, same order) - so no launch sits between it and the contraction that folds the LayerNorm."""
+    a, w0, b0, r = rnd(M, 128, seed=261), rnd(C, 128, scale=0.2, seed=262), rnd(C, seed=263), rnd(M, C, seed=264) + 2.0
+    N = 640 if ops.TILE_TABLE[ctile][1] == 320 else 384
+    w1, b1 = rnd(2 * N if geglu else N, C, scale=0.08, seed=265), rnd(2 * N if geglu else N, seed=266)
+    gamma, beta = rnd(C, seed=267) * 0.3 + 1.0, rnd(C, seed=268) * 0.2
+    pw0 = ops.pack_weight(w0, b0)
+    ops.FORCE_TILE = ptile
+    try:
+        y, st = ops.conv_gemm(a, pw0, ops.linear_geom(M), residual=r, row_stats=True, coef_eps=1e-5)
+        y2, st2 = ops.conv_gemm(a, pw0, ops.linear_geom(M), residual=r, row_stats=True)        # the partial sums of the same call
+    finally:
+        ops.FORCE_TILE = -1
+    assert st is not None and st.data is None and st._coef.shape == (M, 4), "the tile spans the row: coefficients expected"
+    assert torch.equal(y, y2) and st2.data is not None
+    want = st2.coef(C, 1e-5)                                             # aa_ln_finalize on the partial sums
+    assert torch.equal(st._coef.cpu(), want.cpu())
+    yf = y.float()
+    close(-st._coef[:, 0], yf.mean(1), tol=2e-3)
+    close(st._coef[:, 2], 1.0 / torch.sqrt(yf.var(1, unbiased=False) + 1e-5), tol=2e-3)
+    pw = ops.pack_weight(w1, b1, geglu=geglu, ln=(gamma, beta, 1e-5))
+    ops.FORCE_TILE = ctile
+    try:
+        z = ops.conv_gemm(y, pw, ops.linear_geom(M), ln_stats=st)
+    finally:
+        ops.FORCE_TILE = -1
+    h = F.layer_norm(yf, (C,), gamma.float(), beta.float(), 1e-5) @ w1.float().t() + b1.float()
+    close(z, h[:, :N] * F.gelu(h[:, N:]) if geglu else h)
+    # a producer whose tile does NOT span the row keeps the partial sums (two column tiles of 128 for 256 channels)
+    if C == 256:
+        ops.FORCE_TILE = 47
+        try:
+            _, st3 = ops.conv_gemm(a, pw0, ops.linear_geom(M), residual=r, row_stats=True, coef_eps=1e-5)
+        finally:
+            ops.FORCE_TILE = -1
+        assert st3 is not None and st3.data is not None and st3.parts == 4
+
+
 def _ln_fold_consume(y, st, pw, ctile, raw, splits=0, ablate=0):
     """One consuming contraction of a folded LayerNorm on tile `ctile`: statistics raw (ABI 106 ln_parts) or through aa_ln_finalize."""
     keep = ops.LN_FINALIZE_LAUNCH
