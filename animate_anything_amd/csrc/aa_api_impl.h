@@ -491,7 +491,10 @@ static int gn_chunks(const AaGroupNorm& d) {
     // aim for >= ~1024 workgroups, at least 16 tokens each, at most 256 chunks per image group (every apply workgroup
     // re-reduces its image group's chunk partials: measured 54 us at 256 chunks vs 94 us at 1024 for the clip-wide
     // statistics of the 64x64 level, r02 GPU call F)
-    int want = (1024 + d.n_groups_img - 1) / d.n_groups_img;
+    // (round 5: FLOOR - 34 images x ceil(1024 / 34) = 1054 workgroups put a fifth workgroup on 30 of the 256 CUs while the rest hold four:
+    //  the kernel then lasts 5 / 4.12 of its balanced time; 34 x 30 = 1020 fit four per CU)
+    int want = 1024 / d.n_groups_img;                    //  measured -5 ... -7 % on every per-image norm, profiles/r05k_groupnorm_chunks.txt)
+    if (want < 1) want = 1;
     int cap = (d.tokens_per_group + 15) / 16;
     if (cap > 256) cap = 256;
     int c = want < cap ? want : cap;
