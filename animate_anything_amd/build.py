@@ -15,6 +15,17 @@ def _deps():
     return deps
 
 
+def source_id():
+    """sha256[:16] over the library's sources (csrc/**, include/aa_mi355.h, in path order): names WHAT was built, wherever and whenever it is
+    rebuilt - bench.py quotes a committed PMC record only for the sources it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(_deps()):
+        h.update(os.path.relpath(d, ROOT).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()[:16]
+
+
 PROBE_LIB = os.path.join(PKG, "libaa_mi355_probe.so")
 TU_GROUPS = 8             # aa_api_impl.h: tile-table entry i is compiled in unit i % TU_GROUPS
 

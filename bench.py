@@ -209,8 +209,8 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
         rec = json.load(open(tpath))
         fam = rec.get("contraction_kernels") or rec.get("conv_gemm_dma_kernel") or {}
         tname = os.path.basename(tpath)
-        if rec.get("library_sha256_16") != library_id():
-            stale = f"profiles/{tname} was measured on library {rec.get('library_sha256_16', '(unrecorded)')}, this is {library_id()}"
+        if rec.get("library_source_sha256_16") != library_id():
+            stale = f"profiles/{tname} was measured on library sources {rec.get('library_source_sha256_16', '(unrecorded)')}, these are {library_id()}"
         elif fam.get("launches_per_step") != launches:
             stale = f"profiles/{tname} had {fam.get('launches_per_step')} contraction launches per step, this run has {launches}"
         else:
@@ -220,9 +220,9 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": (f"HBM bytes per KERNEL LAUNCH of the contraction kernels, measured (PMC FETCH_SIZE x 2 + WRITE_SIZE in separate "
-                             f"rocprofv3 passes, profiles/{tname}: same library {library_id()}, {t_launches} such launches per step)") if traffic
+                             f"rocprofv3 passes, profiles/{tname}: same library sources {library_id()}, {t_launches} such launches per step)") if traffic
                             else f"null: no PMC measurement of this library ({stale or 'no profiles/r*_traffic_pmc.json'}); run scripts/pmc_traffic.sh",
-            "library_sha256_16": library_id(),
+            "library_source_sha256_16": library_id(),
             "kernel": "contraction kernels: aa::conv_gemm_dma_kernel / conv3x3_slab_kernel / conv_gemm_x_kernel (LDS-DMA implicit-GEMM conv / linear), all instances",
             "contraction_launches_per_step": launches, "reduce_launches_per_step": reduces, "generic_kernel_launches_per_step": generic,
             "aa_conv_gemm_calls_per_step": len(trace),
@@ -237,12 +237,12 @@ _LIB_ID = None
 
 
 def library_id():
-    """sha256[:16] of the libaa_mi355.so this process runs (what a committed PMC record must name to be quoted)."""
+    """sha256[:16] over the SOURCES of libaa_mi355.so (animate_anything_amd.build.source_id: what a committed PMC record must name to be
+    quoted - a rebuild of the same sources elsewhere is the same library, an edited kernel is not)."""
     global _LIB_ID
     if _LIB_ID is None:
-        import hashlib
         from animate_anything_amd import build
-        _LIB_ID = hashlib.sha256(open(build.LIB, "rb").read()).hexdigest()[:16] if os.path.exists(build.LIB) else "missing"
+        _LIB_ID = build.source_id()
     return _LIB_ID
 
 

@@ -40,9 +40,9 @@ for fam in sorted(set(fetch) | set(write)):
     wb = 1024.0 * sum(w) / max(len(w), 1)
     out[fam] = {"launches_profiled": len(f), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                 "hbm_bytes_per_launch": round(fb + wb), "launches_per_step": len(f) // 2}
-# which library was profiled: bench.py quotes these bytes only for the same libaa_mi355.so (sha256[:16])
-import hashlib
+# which library was profiled: bench.py quotes these bytes only for the same library SOURCES (animate_anything_amd.build.source_id)
 import os
-lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "animate_anything_amd", "libaa_mi355.so")
-out["library_sha256_16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from animate_anything_amd import build  # noqa: E402
+out["library_source_sha256_16"] = build.source_id()
 print(json.dumps(out, indent=1))
