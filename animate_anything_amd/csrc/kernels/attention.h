@@ -29,6 +29,10 @@ namespace aa {
 #ifndef AA_ATTN_EAGER_MAX
 #define AA_ATTN_EAGER_MAX 0
 #endif
+#ifndef AA_ATTN_SYNC_FRAGS      // 1: A/B build with compiler-issued fragment reads everywhere (the round-2..4 form)
+#define AA_ATTN_SYNC_FRAGS 0
+#endif
+template <int KT> constexpr bool AT_ASYNC_FRAGS() { return KT == 64 && !AA_ATTN_SYNC_FRAGS; }
 constexpr int AT_KT = 64;                       // keys per tile
 constexpr float AT_DEFER = 6.0f;                // defer-max threshold, in bits (p stays below 2^6 against a stale maximum)
 constexpr int AT_TILE_BYTES = 2 * AT_KT * 128;  // K tile + V tile of one stage
@@ -170,13 +174,33 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
             auto scores = [&]() __attribute__((always_inline)) {
                 if (prio) wave_priority<1>();         // (experiment, AaAttention._pad bit 0: matrix clusters above the co-resident waves' softmax)
                 // the two 32-key blocks alternate so that consecutive MFMAs never wait on each other's accumulator
+                // The tile's K fragments are read by hand, four reads ahead of the MFMA that consumes them (counted lgkmcnt; LDS returns in
+                // order).  Left to hipcc the loop was read -> s_waitcnt lgkmcnt(0) -> MFMA, eight times per tile, through one recycled register
+                // quad (the kernel sits at its 168-register cap): every LDS latency exposed.  (All eight ahead spilled 48 registers.)
+                if constexpr (AT_ASYNC_FRAGS<KT>()) {       // (the single-tile 32-key kernels run four waves per SIMD on 128 registers: compiler-issued reads there)
+                constexpr int NK = 4 * KB, WK = NK < 4 ? NK : 4;
+                u32x4 kf[NK];
+                auto k_read = [&](auto i_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(i_)::value, dk = i / KB, kb = i % KB;
+                    lds_read16_async_off<kb * 4096>(kf[i], sK + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
+                };
+                static_for<WK>(k_read);
+                static_for<NK>([&](auto i_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(i_)::value, dk = i / KB, kb = i % KB;
+                    constexpr int issued = (i + WK < NK) ? i + WK : NK;
+                    lds_wait<issued - i - 1>(kf[i]);
+                    sacc[kb] = mfma_32x32x16(T(), kf[i], qf[dk], dk == 0 ? minus_m : sacc[kb]);
+                    if constexpr (i + WK < NK) k_read(IntTag<i + WK>());
+                });
+                } else {
 #pragma unroll
-                for (int dk = 0; dk < 4; ++dk)
+                    for (int dk = 0; dk < 4; ++dk)
 #pragma unroll
-                    for (int kb = 0; kb < KB; ++kb) {
-                        const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + kb * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
-                        sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], dk == 0 ? minus_m : sacc[kb]);
-                    }
+                        for (int kb = 0; kb < KB; ++kb) {
+                            const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + kb * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
+                            sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], dk == 0 ? minus_m : sacc[kb]);
+                        }
+                }
                 if (prio) wave_priority<0>();
                 if (p.causal && kt * KT + KT - 1 > q0) {     // causal: keys after the query's own position (tiles that reach past the wave's first query)
                     const int qpos = q0 + ql;
@@ -199,6 +223,19 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
                 }
             };
             scores();
+            // V^T fragments of the tile (A operand of O^T += V^T P^T): hand-issued, four (lo, hi) pairs ahead of the MFMA that consumes them, the
+            // first four before the softmax (they do not depend on it: their latency runs under it).  As important: NOT through the builtin - for
+            // that hipcc emits s_waitcnt vmcnt(0) in front of the first read (the LDS it reads may alias what an in-flight LDS-DMA deposits), i.e.
+            // every wave waited, once per tile, for the K / V tile it had just prefetched.
+            constexpr int NP = 4 * KB, WP = NP < 4 ? NP : 4;              // pairs: (chunk ch = pair / 2, d block db = pair % 2)
+            u32x2 vlo[NP], vhi[NP];
+            const char* const vbase = sV + vf_off;
+            auto v_read = [&](auto i_) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_)::value, ch = i / 2, db = i % 2;
+                lds_read_tr16_b64_async<(2 * ch) * 1024 + db * 256>(vlo[i], vbase);
+                lds_read_tr16_b64_async<(2 * ch) * 1024 + db * 256 + 1024>(vhi[i], vbase);
+            };
+            if constexpr (AT_ASYNC_FRAGS<KT>()) static_for<WP>(v_read);
             // Row maximum of (score - m) over this tile: three-input maxima (v_max3_f32), independent chains per half block, a tree,
             // one v_permlane32_swap for the other half-wave's keys.  Only the FIRST tile pays for it up front (it centres the
             // softmax on its true row maximum); every later tile exponentiates against the running maximum straight away and looks
@@ -286,15 +323,26 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
             // O^T += V^T P^T: chunk ch = 16 keys; this half-wave's 8 k-slots are keys 16ch + 4h + {0..3} and
             // 16ch + 8 + 4h + {0..3} (the order P^T's registers came out of the S^T accumulator layout)
             if (prio) wave_priority<1>();
+            if constexpr (AT_ASYNC_FRAGS<KT>()) {
+            static_for<NP>([&](auto i_) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_)::value, ch = i / 2, db = i % 2;
+                constexpr int issued = (i + WP < NP) ? i + WP : NP;
+                lds_wait2<2 * (issued - i - 1)>(vlo[i], vhi[i]);                 // this pair has landed; the younger ones stay in flight
+                const u32x4 vf = {vlo[i][0], vlo[i][1], vhi[i][0], vhi[i][1]};
+                oacc[db] = mfma_32x32x16(T(), vf, pf[ch], oacc[db]);
+                if constexpr (i + WP < NP) v_read(IntTag<i + WP>());
+            });
+            } else {
 #pragma unroll
-            for (int ch = 0; ch < 2 * KB; ++ch)
+                for (int ch = 0; ch < 2 * KB; ++ch)
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const char* base = sV + (2 * ch) * 1024 + db * 256 + vf_off;
-                    const u32x2 lo = lds_read_tr16_b64(base), hi = lds_read_tr16_b64(base + 1024);
-                    const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
-                    oacc[db] = mfma_32x32x16(T(), vf, pf[ch], oacc[db]);
-                }
+                    for (int db = 0; db < 2; ++db) {
+                        const char* base = sV + (2 * ch) * 1024 + db * 256 + vf_off;
+                        const u32x2 lo = lds_read_tr16_b64(base), hi = lds_read_tr16_b64(base + 1024);
+                        const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+                        oacc[db] = mfma_32x32x16(T(), vf, pf[ch], oacc[db]);
+                    }
+            }
             if (prio) wave_priority<0>();
         }
     }

@@ -102,6 +102,22 @@ template <int N>
 __device__ __forceinline__ void lds_wait(u32x4& x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N)); }
 // Order the consumers of `x` behind the preceding lds_wait (no instruction emitted).
 __device__ __forceinline__ void lds_pin(u32x4& x) { asm volatile("" : "+v"(x)); }
+// The same for the 8-byte transposing read (ds_read_b64_tr_b16, see lds_read_tr16_b64), with a compile-time byte offset in the
+// instruction's offset field (one address register for all pieces of a tile).  Besides overlapping the reads with matrix work, the
+// hand-issued form keeps hipcc from draining the LDS-DMA queue in front of them: for the builtin it emits s_waitcnt vmcnt(0) (the read
+// may alias what an in-flight `buffer_load ... lds` deposits), which stalls every wave on the K / V tiles it has just prefetched.
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr16_b64_async(u32x2& dst, const void* lds_ptr) {
+    const unsigned addr = (unsigned)(unsigned long long)lds_ptr;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16_async_off(u32x4& dst, const void* lds_ptr) {
+    const unsigned addr = (unsigned)(unsigned long long)lds_ptr;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait2(u32x2& x, u32x2& y) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N)); }
 
 // ---- accumulator file of the hand-scheduled contraction kernel (conv_gemm_x.h) --------------------------------------
 // 32x32 accumulator block b (16 fp32 per lane) lives under a LITERAL name in the accumulation half of the unified register

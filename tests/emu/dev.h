@@ -279,6 +279,9 @@ inline void lds_read16_async(u32x4& dst, const void* lds_ptr) { dst = *reinterpr
 template <int N>
 inline void lds_wait(u32x4&) {}
 inline void lds_pin(u32x4&) {}
+template <int OFF> inline void lds_read_tr16_b64_async(u32x2& dst, const void* lds_ptr) { dst = lds_read_tr16_b64(static_cast<const char*>(lds_ptr) + OFF); }
+template <int OFF> inline void lds_read16_async_off(u32x4& dst, const void* lds_ptr) { dst = *reinterpret_cast<const u32x4*>(static_cast<const char*>(lds_ptr) + OFF); }
+template <int N> inline void lds_wait2(u32x2&, u32x2&) {}
 
 using std::fabs;
 inline float fabsf_(float x) { return std::fabs(x); }
