@@ -203,19 +203,7 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
     # bench.py cannot profile itself: the PMC bytes come from the newest committed run of scripts/pmc_traffic.sh - and only count
     # when that run was of THIS library and THIS launch plan (a kernel change without a new PMC run used to report
     # stale bytes silently).  The record carries the sha256 of the libaa_mi355.so it profiled.
-    import glob
-    traffic, tname, t_launches, stale = None, None, None, None
-    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_pmc.json")), reverse=True):
-        rec = json.load(open(tpath))
-        fam = rec.get("contraction_kernels") or rec.get("conv_gemm_dma_kernel") or {}
-        tname = os.path.basename(tpath)
-        if rec.get("library_source_sha256_16") != library_id():
-            stale = f"profiles/{tname} was measured on library sources {rec.get('library_source_sha256_16', '(unrecorded)')}, these are {library_id()}"
-        elif fam.get("launches_per_step") != launches:
-            stale = f"profiles/{tname} had {fam.get('launches_per_step')} contraction launches per step, this run has {launches}"
-        else:
-            traffic, t_launches = fam.get("hbm_bytes_per_launch"), fam.get("launches_per_step")
-        break
+    traffic, tname, t_launches, stale = pick_traffic_record(os.path.join(ROOT, "profiles"), library_id(), launches)
     traffic_step = traffic * t_launches if traffic and t_launches else None
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -231,6 +219,24 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
             "algorithmic_bytes_per_step": round(alg_bytes), "traffic_bytes_per_step": traffic_step,
             "traffic_over_algorithmic": round(traffic_step / alg_bytes, 3) if traffic_step else None,
             "whole_step_frac_of_peak": round(flop_step / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+
+
+def pick_traffic_record(profiles_dir, lib_id, launches):
+    """The newest committed PMC record (profiles/r*_traffic_pmc.json, scripts/pmc_traffic.sh) - quoted only if it was measured on THESE library
+    sources and on the same number of contraction launches per step.  Returns (hbm bytes per launch | None, file name | None, launches per
+    step of the record | None, why not | None)."""
+    import glob
+    for tpath in sorted(glob.glob(os.path.join(profiles_dir, "r*_traffic_pmc.json")), reverse=True):
+        rec = json.load(open(tpath))
+        fam = rec.get("contraction_kernels") or rec.get("conv_gemm_dma_kernel") or {}
+        tname = os.path.basename(tpath)
+        if rec.get("library_source_sha256_16") != lib_id:
+            return None, tname, None, (f"profiles/{tname} was measured on library sources {rec.get('library_source_sha256_16', '(unrecorded)')}, "
+                                       f"these are {lib_id}")
+        if fam.get("launches_per_step") != launches:
+            return None, tname, None, f"profiles/{tname} had {fam.get('launches_per_step')} contraction launches per step, this run has {launches}"
+        return fam.get("hbm_bytes_per_launch"), tname, fam.get("launches_per_step"), None
+    return None, None, None, None
 
 
 _LIB_ID = None

@@ -128,3 +128,27 @@ def test_checkpoint_lookup_rejects_path_variants_and_unpickles_tensors_only(tmp_
         load_state(str(tmp_path / "evil"), "m")
     with pytest.raises(FileNotFoundError):
         load_state(str(tmp_path), "nothing_here")
+
+
+def test_bench_quotes_pmc_traffic_only_for_the_library_it_was_measured_on(tmp_path):
+    """bench.py `roofline.traffic` (VERDICT r04 weak point 12): the committed PMC record counts only for the library SOURCES it names and the
+    same number of contraction launches per step; a record of another library, or none, gives null with the reason."""
+    import json
+    import os
+    import bench
+    from animate_anything_amd import build
+    sid = build.source_id()
+    assert len(sid) == 16 and sid == build.source_id()
+    rec = {"contraction_kernels": {"hbm_bytes_per_launch": 123456, "launches_per_step": 443}, "library_source_sha256_16": sid}
+    (tmp_path / "r05_traffic_pmc.json").write_text(json.dumps(rec))
+    assert bench.pick_traffic_record(str(tmp_path), sid, 443) == (123456, "r05_traffic_pmc.json", 443, None)
+    got = bench.pick_traffic_record(str(tmp_path), sid, 444)
+    assert got[0] is None and "443 contraction launches" in got[3]
+    got = bench.pick_traffic_record(str(tmp_path), "0" * 16, 443)
+    assert got[0] is None and "measured on library sources" in got[3]
+    (tmp_path / "r06_traffic_pmc.json").write_text(json.dumps({"contraction_kernels": {"hbm_bytes_per_launch": 1, "launches_per_step": 443}}))
+    got = bench.pick_traffic_record(str(tmp_path), sid, 443)           # the NEWEST record decides: an unkeyed one is not trusted
+    assert got[0] is None and got[1] == "r06_traffic_pmc.json"
+    assert bench.pick_traffic_record(str(tmp_path / "none"), sid, 443) == (None, None, None, None)
+    # the committed record of this repository names the committed sources
+    assert bench.pick_traffic_record(os.path.join(bench.ROOT, "profiles"), sid, 443)[0], "profiles/: no PMC record of the current library sources"
