@@ -508,6 +508,26 @@ def test_three_steps_against_the_oracle_at_the_metric_configuration():
             f.write("\n".join(lines) + "\n")
 
 
+def test_three_steps_against_the_oracle_at_the_metric_configuration_bf16():
+    """The same three oracle steps through the bf16 library path (`bench.py --dtype bf16`), both guidance forms, at the bf16 tolerance of
+    this file (8 significant bits of storage against 11: MSE < 1e-2, max-normalised error < k x 1.5e-1 after k steps)."""
+    fixture = os.path.join(HERE, "golden", "pipeline_fullsize_16x64x64_3steps.pt")
+    if not os.path.exists(fixture):
+        pytest.skip("golden not generated (tests/golden/make_fullsize_multistep_golden.py)")
+    gold = torch.load(fixture)
+    want, ts = gold["latents"].float(), [int(t) for t in gold["timesteps"]]
+    i = fullsize_inputs(16, 64)
+    net = _fullsize_product(torch.bfloat16)
+    for shared in (False, True):
+        got = _denoise_steps(net, i, ts, shared)
+        for k in range(len(ts)):
+            w = want[k]
+            mse = ((got[k] - w) ** 2).mean().item()
+            e = (got[k] - w).abs().max().item() / w.abs().max().item()
+            print(f"bf16 {'shared-prefix' if shared else 'strict'} step {k + 1}: MSE {mse:.3g} max-normalised {e:.3g}")
+            assert torch.isfinite(got[k]).all() and mse < 1e-2 and e < 1.5e-1 * (k + 1), (shared, k, mse, e)
+
+
 def test_cfg_shared_prefix_equals_full_batch_at_the_metric_configuration():
     """LatentToVideoPipeline.denoise under guidance computes the text-independent UNet prefix once per pair: two full-size steps
     both ways on bench.py's weights (torch default init under seed 0, not the oracle's state) must agree to the fp16 noise floor
