@@ -14,6 +14,7 @@
 #include "kernels/conv_gemm_x.h"
 #include "kernels/norm.h"
 #include "kernels/attention.h"
+#include "kernels/seq_attention.h"
 #include "kernels/glue.h"
 
 namespace aa {
@@ -762,6 +763,39 @@ int aa_attention(const AaAttention* d, void* stream) {
     if (d->dtype == AA_F16) return attention_t<f16_t>(*d, stream);
     if (d->dtype == AA_BF16) return attention_t<bf16_t>(*d, stream);
     return fail(AA_E_DTYPE, "attention: unsupported dtype %d", d->dtype);
+}
+
+int aa_seq_self_attention_ok(const AaSeqSelfAttn* d) {
+    using namespace aa;
+    if (!d) return 0;
+    if (d->channels != 320 && d->channels != 512 && d->channels != 640) return 0;
+    if (d->seq_len < 1 || d->seq_len > 32 || d->n_outer <= 0 || d->n_inner <= 0) return 0;
+    if (d->ldx % 8 || d->ldo % 8 || d->ldx < d->channels || d->ldo < d->channels) return 0;
+    if (d->x_bytes <= 0 || d->o_bytes <= 0 || d->x_bytes >= ((int64_t)1 << 31) || d->o_bytes >= ((int64_t)1 << 31)) return 0;
+    if (d->dtype != AA_F16 && d->dtype != AA_BF16) return 0;
+    return 1;
+}
+
+int aa_seq_self_attention(const AaSeqSelfAttn* d, void* stream) {
+    using namespace aa;
+    if (!d) return fail(AA_E_SHAPE, "seq_self_attention: null descriptor");
+    if (!aa_seq_self_attention_ok(d))
+        return fail(AA_E_SHAPE, "seq_self_attention: unsupported call (channels %d, seq_len %d, ldx %d, ldo %d, dtype %d)", d->channels, d->seq_len, d->ldx, d->ldo, d->dtype);
+    if (!aligned16(d->x) || !aligned16(d->w) || !aligned16(d->o) || !aligned16(d->w_bias))
+        return fail(AA_E_ALIGN, "seq_self_attention: operands must be 16-byte aligned");
+    if (d->normalize && !(d->ln_eps > 0.0f)) return fail(AA_E_SHAPE, "seq_self_attention: normalize needs ln_eps > 0");
+    const int per = (32 * SA_NW) / d->seq_len;
+    const int64_t n_seq = (int64_t)d->n_outer * d->n_inner;
+    const dim3 grid((unsigned)((n_seq + per - 1) / per)), block(64 * SA_NW);
+    const size_t lds = sa_lds_bytes(d->channels);
+#define AA_SA(T, C_) AA_LAUNCH((seq_self_attention_kernel<T, C_>), grid, block, lds, stream, *d)
+    if (d->dtype == AA_F16) {
+        if (d->channels == 320) AA_SA(f16_t, 320); else if (d->channels == 512) AA_SA(f16_t, 512); else AA_SA(f16_t, 640);
+    } else {
+        if (d->channels == 320) AA_SA(bf16_t, 320); else if (d->channels == 512) AA_SA(bf16_t, 512); else AA_SA(bf16_t, 640);
+    }
+#undef AA_SA
+    return finish("seq_self_attention");
 }
 
 int aa_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int32_t x_ld, int32_t y_ld, int32_t dtype, void* stream) {

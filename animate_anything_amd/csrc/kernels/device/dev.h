@@ -49,6 +49,12 @@ __device__ __forceinline__ long long hw_id() {
     return (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 }
 
+// busy-wait for `ticks` of the 100 MHz wall clock (s_sleep between the reads: the wave leaves its issue slots to the others)
+__device__ __forceinline__ void spin_wall_ticks(int ticks) {
+    const long long t0 = wall_now();
+    while (wall_now() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 // LDS-DMA through a buffer descriptor: every lane fetches 16 bytes, the wave's 64 pieces land lane-linear at
 // lds_wave_base + lane*16 (wave-uniform base) without passing through VGPRs; operand base + range sit in SGPRs, each lane
 // supplies one 32-bit byte offset, and a lane whose offset is out of range deposits 16 zero bytes
@@ -83,6 +89,11 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // most N are still in flight, i.e. everything issued before the N youngest has landed.
 template <int N>
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// everything this wave has issued - LDS-DMA, global loads / stores, LDS reads / writes - is complete (in front of a raw s_barrier that
+// publishes plain LDS stores: the compiler does not know the asm statement is a barrier and would not wait for them)
+__device__ __forceinline__ void mem_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+// the compiler's scheduler moves nothing across this point (no instruction emitted)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // Workgroup barrier WITHOUT the implicit vmcnt(0) drain of __syncthreads(); the "memory" clobber keeps the
 // compiler from moving LDS / DMA accesses across it.
 __device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "memory"); }

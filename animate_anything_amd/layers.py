@@ -86,6 +86,13 @@ LN_FOLD_FF = os.environ.get("AA_LN_FOLD_FF", "1") == "1"
 # its three tensor passes and per-tile fixed costs, 420-730 TF/s - rides as 25 % more K on a K = 4C contraction that runs at 730-950,
 # and the block output is never written or re-read (-2 tensor passes, -30 launches per step).  AA_FF_PROJ_MERGE=0: the two calls.
 FF_PROJ_MERGE = os.environ.get("AA_FF_PROJ_MERGE", "1") == "1"
+# The self-attention layers of TransformerTemporalModel (17-frame sequences): LayerNorm, the Q|K|V projection and the attention as ONE
+# kernel (ops.seq_self_attention, ABI 108) - Q|K|V are never written.  AA_SEQ_ATTN=0: LayerNorm fold + Q|K|V contraction + aa_attention.
+SEQ_ATTN = os.environ.get("AA_SEQ_ATTN", "1") == "1"
+# ... where it is faster than the three launches: 320 channels (two workgroups per CU: 135-160 us against 262-278 at the 64x64 level) and 512
+# (transformer_in: 347-384 against 491-518); at 640 channels (32x32 level) x takes 160 registers, one workgroup per CU is left and 293 tiles
+# make two rounds of 256: 194-211 us against 163-174 (profiles/r06b_seq_attention_two_per_cu.txt) - the three launches stay there
+SEQ_ATTN_CHANNELS = tuple(int(c) for c in os.environ.get("AA_SEQ_ATTN_CHANNELS", "320,512").split(",") if c)
 UPSAMPLE_AS_PARITY_CONVS = True      # Upsample2D at exactly x2: four 2x2 convolutions (ops.pack_upsample2x_weights); False = the 3x3 gather form
 
 
@@ -287,6 +294,7 @@ class Attention(nn.Module):
     def _apply(self, fn, *a, **k):
         self._fused = None
         self._fused_ln = None
+        self._seq_w = None
         return super()._apply(fn, *a, **k)
 
     def fused(self):
@@ -308,6 +316,21 @@ class Attention(nn.Module):
 
     _fused_ln = None
     _fused_ln_key = None
+    _seq_w = None
+    _seq_w_key = None
+
+    def seq_packed(self, norm):
+        """The operands of ops.seq_self_attention: per head the to_k, to_v (permuted) and to_q rows with `norm` - the LayerNorm in front - folded in."""
+        key = weights_key(self.to_q.weight, self.to_k.weight, self.to_v.weight, norm.weight, norm.bias)
+        if self._seq_w is None or self._seq_w_key != key:
+            self._seq_w = ops.pack_seq_qkv(self.to_q.weight, self.to_k.weight, self.to_v.weight, ln=(norm.weight, norm.bias, norm.eps))
+            self._seq_w_key = key
+        return self._seq_w
+
+    def seq_ok(self, x, g: "Grid", temporal: bool):
+        """Can this self-attention over the frames of a pixel run as ops.seq_self_attention (LayerNorm + Q|K|V + attention in one kernel)?"""
+        return (SEQ_ATTN and temporal and not self.is_cross and self.dim_head == 64 and self.inner == x.shape[1] == self.to_q.in_features
+                and self.inner in SEQ_ATTN_CHANNELS and self.to_q.bias is None and ops.seq_self_attention_ok(self.inner, g.frames, x.shape[0], x.dtype))
 
     def text_kv(self, text_tokens):
         """[clips*L, cross_dim] -> [clips*L, 2*inner] (K | V): normally a column slice of ONE projection of the text for
@@ -323,9 +346,15 @@ class Attention(nn.Module):
         kv = self.text_kv(text_tokens)
         return self.to_out[0].tokens(kv[:, self.inner:].contiguous())
 
-    def self_tokens(self, normed, residual, g: Grid, temporal: bool, ln=None, **epilogue):
+    def self_tokens(self, normed, residual, g: Grid, temporal: bool, ln=None, seq_ln=None, **epilogue):
         """`ln` = (LayerNorm module, ops.RowStats of `normed`'s rows): `normed` is then the UN-normalised tensor and the
-        LayerNorm is folded into the Q|K|V projection.  `row_stats=True` (epilogue) returns (out, RowStats or None)."""
+        LayerNorm is folded into the Q|K|V projection.  `row_stats=True` (epilogue) returns (out, RowStats or None).
+        `seq_ln` = the LayerNorm module in front (caller checked seq_ok): `normed` is the un-normalised tensor; LayerNorm, Q|K|V
+        and the attention over the frames of each pixel run as one kernel, only the output projection follows."""
+        if seq_ln is not None:
+            a = ops.seq_self_attention(normed, self.seq_packed(seq_ln), g.clips, g.hw, g.frames, (g.frames * g.hw, 1, g.hw),
+                                       scale=float(self.dim_head) ** -0.5)
+            return self.to_out[0].tokens(a, residual=residual, **epilogue)
         if ln is None:
             qkv = ops.conv_gemm(normed, self.fused(), ops.linear_geom(normed.shape[0]))
         else:
@@ -425,7 +454,14 @@ class BasicTransformerBlock(nn.Module):
         of the projection in front of it (proj_in, to_out + residual); a producer that cannot emit them (split K, compiled
         tiles) leaves None and that LayerNorm runs as a kernel."""
         fold = LN_FOLD
-        if fold and x_stats is not None:
+        fold_ff = fold and LN_FOLD_FF
+        seq1 = self.attn1.seq_ok(x, g, temporal)
+        seq2 = not self.attn2.is_cross and self.attn2.seq_ok(x, g, temporal)
+        if seq1:                                          # norm1 + Q|K|V + attention in one kernel; norm2's statistics only if its consumer folds it
+            want = fold and not seq2
+            r = self.attn1.self_tokens(x, x, g, temporal, seq_ln=self.norm1, row_stats=want, coef_eps=self.norm2.eps)
+            x, st = r if want else (r, None)
+        elif fold and x_stats is not None:
             x, st = self.attn1.self_tokens(x, x, g, temporal, ln=(self.norm1, x_stats), row_stats=True, coef_eps=self.norm2.eps)
         else:
             x, st = self.attn1.self_tokens(self.norm1.tokens(x), x, g, temporal, row_stats=True, coef_eps=self.norm2.eps) if fold else \
@@ -434,14 +470,16 @@ class BasicTransformerBlock(nn.Module):
             x = torch.cat([x] * dup)
             st = None if st is None else st.repeat(dup)
             g = replace(g, clips=g.clips * dup)
-        ln2 = None if st is None else (self.norm2, st)
-        xin = x if ln2 is not None else self.norm2.tokens(x)
-        fold_ff = fold and LN_FOLD_FF
-        if self.attn2.is_cross:
-            kv = self.attn2.text_kv(text)
-            r = self.attn2.cross_tokens(xin, x, g, kv, text_len, ln=ln2, row_stats=fold_ff, coef_eps=self.norm3.eps)
+        if seq2:
+            r = self.attn2.self_tokens(x, x, g, temporal, seq_ln=self.norm2, row_stats=fold_ff, coef_eps=self.norm3.eps)
         else:
-            r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, row_stats=fold_ff, coef_eps=self.norm3.eps)
+            ln2 = None if st is None else (self.norm2, st)
+            xin = x if ln2 is not None else self.norm2.tokens(x)
+            if self.attn2.is_cross:
+                kv = self.attn2.text_kv(text)
+                r = self.attn2.cross_tokens(xin, x, g, kv, text_len, ln=ln2, row_stats=fold_ff, coef_eps=self.norm3.eps)
+            else:
+                r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, row_stats=fold_ff, coef_eps=self.norm3.eps)
         x, st = r if fold_ff else (r, None)
         if st is not None:
             return self.ff.tokens(x, residual=x, ln=(self.norm3, st), tail=tail)
@@ -469,9 +507,17 @@ class _MergedTail:
             w = torch.cat([wpf @ w2.detach().float(), wpf], dim=1)                  # [C_out, 4C + C]
             b = (0.0 if bp is None else bp.detach().float()) + (0.0 if b2 is None else wpf @ b2.detach().float())
             b = b if torch.is_tensor(b) else None
-            self._mt = ops.pack_weight(w.to(wp.dtype), None if b is None else b.to(wp.dtype))
+            # The product Wp W2 is rounded ONCE to the storage type.  Its dynamic range is not that of either factor (real checkpoints,
+            # LoRA-merged weights): if it leaves the type's range, or its rounding error is far above that of an ordinary weight matrix
+            # of the type (half an ulp: 2^-11 fp16 / 2^-8 bf16 relative, per element; measured in the Frobenius norm), the two calls run.
+            wl = w.to(wp.dtype)
+            ok = bool(torch.isfinite(wl).all()) and (b is None or bool(torch.isfinite(b.to(wp.dtype)).all()))
+            if ok:
+                rel = ((wl.float() - w).norm() / w.norm().clamp_min(1e-30)).item()
+                ok = rel <= (4.0 * 2.0 ** -11 if wp.dtype == torch.float16 else 4.0 * 2.0 ** -8)
+            self._mt = ops.pack_weight(wl, None if b is None else b.to(wp.dtype)) if ok else False
             self._mt_key = key
-        return self._mt
+        return self._mt or None
 
 
 class Transformer2DModel(_MergedTail, nn.Module):
@@ -513,7 +559,11 @@ class TransformerTemporalModel(_MergedTail, nn.Module):
         self.proj_out = Linear(inner, in_channels)
 
     def tokens(self, x, g: Grid):
-        h, st = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw), row_stats=True, coef_eps=self.transformer_blocks[0].norm1.eps) if LN_FOLD else \
+        blk0 = self.transformer_blocks[0]
+        # (norm1's statistics are only wanted when the first attention layer folds it: ops.seq_self_attention normalises in its registers)
+        want = LN_FOLD and not (SEQ_ATTN and blk0.attn1.inner in SEQ_ATTN_CHANNELS and blk0.attn1.dim_head == 64 and self.proj_in.out_features == blk0.attn1.inner
+                                and ops.seq_self_attention_ok(blk0.attn1.inner, g.frames, x.shape[0], x.dtype))
+        h, st = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw), row_stats=True, coef_eps=blk0.norm1.eps) if want else \
                 (self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw)), None)
         mt, last = self.merged_tail(), len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (AA_ACT_GELU, AA_ACT_NONE, AA_ACT_QUICK_GELU, AA_ACT_SILU, AA_BF16, AA_F16, AA_F32, AaAttention, AaAttnOperand,
-                   AaBlend, AaConvGemm, AaDpmStep, AaDpmStepTok, AaEulerStepTok, AaGroupNorm, AaPackFrames, AaPackLatents)
+                   AaBlend, AaConvGemm, AaDpmStep, AaDpmStepTok, AaEulerStepTok, AaGroupNorm, AaPackFrames, AaPackLatents, AaSeqSelfAttn)
 
 _DT = {torch.float16: AA_F16, torch.bfloat16: AA_BF16, torch.float32: AA_F32}
 
@@ -32,7 +32,12 @@ LAST_STAMPS = None
 GN_PLANS = None            # a list: groupnorm() appends (groups per workgroup, pieces per thread, parts, grid) or None per call
 MAX_OPERAND_BYTES = 1 << 31      # the contraction kernel's 32-bit operand offsets
 FORCE_TILE = -1       # tests / sweeps: >= 0 puts this tile-table index into AaConvGemm.tile of every conv_gemm call (strict: ineligible = error)
-ATTN_FLAGS = int(os.environ.get("AA_ATTN_FLAGS", "0"))   # experiments: AaAttention._pad (bit 0: s_setprio 1 around the matrix clusters of the head_dim-64 kernel; bit 1: the eager row maximum of rounds 2-4)
+# experiments: AaAttention._pad.  bit 0 (1): s_setprio 1 around the matrix clusters of the head_dim-64 kernel; bit 2 (4): short key sequences take the
+# general kernel instead of attention_shortkv_kernel (A/B).  (The eager row maximum of rounds 2-4 is a COMPILE-time variant: build.build(variant=
+# ("eager", ["-DAA_ATTN_EAGER_MAX=1"])) loaded through AA_LIBRARY - there is no run-time bit for it.)  Unknown bits are rejected.
+ATTN_FLAGS = int(os.environ.get("AA_ATTN_FLAGS", "0"))
+if ATTN_FLAGS & ~5:
+    raise RuntimeError(f"AA_ATTN_FLAGS={ATTN_FLAGS}: only bits 0 (value 1) and 2 (value 4) exist")
 # A folded LayerNorm's row statistics reach the consumer as aa_ln_finalize's per-row coefficients (one 4.7 us launch per consumer, 99 per
 # step) or raw (ABI 106 `ln_parts`: the consumer finalises 2 / 10 partial sums per row itself with independent loads).  Measured (r04h/i):
 # the raw form removes 80 launches (-0.37 ms) and costs the K = 320 ... 1280 consumers 4-7 % (+0.7 ms: square root, reciprocal and the
@@ -545,7 +550,10 @@ def conv_gemm(x0: torch.Tensor, pw: PackedWeight, g: Geom, x1: Optional[torch.Te
                 rv = rowvec[(i0 * ro) // rowvec_div:]
             ls = None
             if ln_stats is not None:                       # the statistics of a chunk's rows (the folded call is linear: ri == ro)
-                ls = RowStats(ln_stats.data[i0 * ri:(i0 + n) * ri], n * ri, ln_stats.parts)
+                if ln_stats.data is None:                  # finished coefficients from the producer (ABI 107): slice those
+                    ls = RowStats(None, n * ri, 0, ln_stats._coef[i0 * ri:(i0 + n) * ri], ln_stats._coef_key)
+                else:
+                    ls = RowStats(ln_stats.data[i0 * ri:(i0 + n) * ri], n * ri, ln_stats.parts)
             conv_gemm(x0[i0 * ri:(i0 + n) * ri], pw, gi, None if x1 is None else x1[i0 * ri:(i0 + n) * ri], rv, rowvec_div,
                       None if residual is None else residual[i0 * ro:(i0 + n) * ro], act, out_dtype, out_scale, False,
                       out[i0 * ro * osc:(i0 + n) * ro * osc], bias, acc_scale, out_map, ls)
@@ -714,6 +722,81 @@ def attention(q: torch.Tensor, q_col0: int, k: torch.Tensor, k_col0: int, v: tor
     d.q_len, d.kv_len, d.dtype = q_len, kv_len, _DT[q.dtype]
     d.scale = float(head_dim) ** -0.5 if scale is None else scale
     _run(lib.aa_attention, C.byref(d), _stream(q))
+    return out
+
+
+# ------------------------------------------------------------------------------------- short-sequence self-attention with the projections inside
+SEQ_ATTN_DEBUG = 0     # profiling only: AaSeqSelfAttn.flags (timing ablations)
+
+
+@dataclass
+class SeqQKV:
+    """Operands of aa_seq_self_attention: `w` [heads, 3, 64, C] (per head the to_k rows, the permuted to_v rows, the to_q rows; a
+    LayerNorm's gamma folded in), `bias` fp32 [heads, 3, 64] = W beta of that LayerNorm (None without one), its epsilon."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    ln_eps: float
+
+
+def pack_seq_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, ln=None) -> SeqQKV:
+    """to_q / to_k / to_v [heads * 64, C] (no bias: diffusers Attention) -> the operands of aa_seq_self_attention.  The to_v rows of a
+    head go in the order 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3) per 32-row half (a lane's 16 output registers are then 16
+    consecutive channels).  `ln` = (gamma, beta, eps) folds the LayerNorm in front: LN(x) W^T = x~ W'^T + W beta with x~ the
+    normalised rows (the kernel's part), W' = W diag(gamma) rounded to the storage type, the bias in fp32 (cf. pack_weight(ln=...))."""
+    n, c = wq.shape
+    assert n % 64 == 0 and wk.shape == (n, c) and wv.shape == (n, c)
+    i = torch.arange(32, device=wq.device)
+    perm = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)
+    perm64 = torch.cat([perm, perm + 32])
+    heads = n // 64
+
+    def order(t):                                                     # [3, n, ...] (q, k, v) -> [heads, 3, 64, ...] (k, permuted v, q)
+        q, k, v = (t[j].reshape((heads, 64) + tuple(t.shape[2:])) for j in range(3))
+        return torch.stack([k, v[:, perm64], q], dim=1).contiguous()
+
+    w3 = torch.stack([wq.detach(), wk.detach(), wv.detach()])
+    bias, eps = None, 0.0
+    if ln is not None:
+        gamma, beta, eps = ln
+        wf = w3.float()
+        bias = order(wf @ beta.detach().float())                      # fp32 [heads, 3, 64]
+        w3 = (wf * gamma.detach().float()[None, None, :]).to(wq.dtype)
+    return SeqQKV(order(w3), bias, float(eps))
+
+
+def _seq_self_attn_desc(x, pk, out, n_outer, n_inner, seq_len, strides, scale):
+    d = AaSeqSelfAttn()
+    d.x, d.w, d.w_bias, d.o = _ptr(x), _ptr(pk.w), _ptr(pk.bias), _ptr(out)
+    d.outer_stride, d.inner_stride, d.pos_stride = strides
+    last = (n_outer - 1) * strides[0] + (n_inner - 1) * strides[1] + (seq_len - 1) * strides[2]
+    d.x_bytes, d.o_bytes = (last + 1) * x.stride(0) * 2, (last + 1) * out.stride(0) * 2
+    d.n_outer, d.n_inner, d.seq_len, d.channels = n_outer, n_inner, seq_len, x.shape[1]
+    d.ldx, d.ldo = x.stride(0), out.stride(0)
+    d.normalize, d.ln_eps, d.scale, d.dtype = int(pk.ln_eps > 0.0), float(pk.ln_eps), float(scale), _DT[x.dtype]
+    d.flags = SEQ_ATTN_DEBUG
+    return d
+
+
+def seq_self_attention_ok(channels: int, seq_len: int, rows: int, dtype) -> bool:
+    """Does aa_seq_self_attention cover a [rows, channels] token matrix with sequences of `seq_len` positions?"""
+    d = AaSeqSelfAttn()
+    d.channels, d.seq_len, d.n_outer, d.n_inner, d.ldx, d.ldo = channels, seq_len, 1, 1, channels, channels
+    d.x_bytes = d.o_bytes = rows * channels * 2
+    d.dtype = _DT.get(dtype, -1)
+    return bool(_lib.get().aa_seq_self_attention_ok(C.byref(d)))
+
+
+def seq_self_attention(x: torch.Tensor, pk: SeqQKV, n_outer: int, n_inner: int, seq_len: int, strides, scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(q k^T * scale) v with [q | k | v] = LayerNorm(x) W^T for every (outer, inner) sequence and head (head_dim 64), in one
+    kernel; `pk` from pack_seq_qkv (with the LayerNorm folded in, or without one), `strides` = (outer, inner, pos) row strides of x
+    (and of the result, [rows, C])."""
+    lib = _lib.get()
+    _check(x, pk.w, pk.bias)
+    if pk.w.dtype != x.dtype or pk.w.shape[-1] != x.shape[1]:
+        raise RuntimeError("seq_self_attention: weights were packed for another dtype / width")
+    out = torch.empty(x.shape[0], x.shape[1], dtype=x.dtype, device=x.device)
+    d = _seq_self_attn_desc(x, pk, out, n_outer, n_inner, seq_len, strides, 64.0 ** -0.5 if scale is None else scale)
+    _run(lib.aa_seq_self_attention, C.byref(d), _stream(x))
     return out
 
 

@@ -57,7 +57,9 @@ def tensor2vid(video):
 
 
 class LatentToVideoPipeline:
-    cfg_shared_prefix = True     # compute the text-independent prefix of the UNet once per guidance pair (identical results)
+    cfg_shared_prefix = True     # compute the text-independent prefix of the UNet once per guidance pair: the same arithmetic per element, but
+                                 # other tile shapes / summation orders in the shared part - the two forms differ inside the fp16 noise floor
+                                 # (0.013-0.029 of the latents' range over three steps at guidance 9, tests/test_gpu_fullsize.py), not bit for bit
     guidance_group = None        # (role, process group) of distributed.guidance_pair: the two guidance halves on two GPUs
 
     def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet=None, scheduler=None):
@@ -192,7 +194,7 @@ class LatentToVideoPipeline:
         x = sess.inputs["sample"]                               # fp32 [b0,C,T,h,w]: updated in place by the solver kernel
         x0_prev = torch.zeros_like(x)
         for i, t in enumerate(ts):
-            eps = sess.run()                                    # tokens [b*(T+1)*h*w, out_channels]
+            eps = sess.run()                                    # tokens [b*(T+1)*h*w, 8], columns [0, out_channels) valid (row pitch = stride(0))
             k = sched.coefficients(sched.index_for_timestep(t), i > 0)
             ops.cfg_dpm_step_tokens(eps, x, x0_prev, None, guidance_scale if cfg else None, k,
                                     next_t=sess.inputs["t"], next_t_value=float(ts[i + 1]) if i + 1 < len(ts) else float(t))
@@ -224,7 +226,8 @@ class LatentToVideoPipeline:
         x = sess.inputs["sample"]
         x0_prev = torch.zeros_like(x)
         for i, t in enumerate(ts):
-            eps = D.all_gather_cat(sess.run(), group)          # [uncond clips | text clips], the layout the solver kernel reads
+            # (the UNet's token matrix is padded to 8 columns: only conv_out's channels travel - 0.28 MB per rank at 16x64x64)
+            eps = D.all_gather_cat(sess.run()[:, :unet.conv_out.out_channels], group)          # [uncond clips | text clips], the layout the solver kernel reads
             k = sched.coefficients(sched.index_for_timestep(t), i > 0)
             ops.cfg_dpm_step_tokens(eps, x, x0_prev, None, guidance_scale, k,
                                     next_t=sess.inputs["t"], next_t_value=float(ts[i + 1]) if i + 1 < len(ts) else float(t))

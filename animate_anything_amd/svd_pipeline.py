@@ -302,7 +302,7 @@ class StableVideoDiffusionPipeline:
         x = sess.inputs[f"src{scaled}"]                          # fp32 [b0,F,4,h,w]: updated in place by the solver kernel
         g = guidance_scale.to(device=dev, dtype=torch.float32).contiguous() if cfg else None
         for i, t in enumerate(ts):
-            v = sess.run()                                       # tokens [b*F*h*w, out_channels]
+            v = sess.run()                                       # tokens [b*F*h*w, ld >= out_channels] (consumers take the row pitch)
             idx = sched.index_for_timestep(t)
             k = sched.coefficients(idx)
             nxt = i + 1 < len(ts)

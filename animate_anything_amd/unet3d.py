@@ -341,9 +341,11 @@ class UNet3DConditionModel(nn.Module):
         models/pipeline.py:160-168: same latents, condition frame, mask, timestep and motion for the unconditional and the
         text half).  Everything the text cannot reach - conv_in, transformer_in, the first resnet / temporal conv and the
         first spatial self-attention - is then computed for ONE half and replicated in front of the first text
-        cross-attention: identical results, the redundant half of that prefix is not recomputed.
+        cross-attention: the same arithmetic per element (results equal to the strict form within the fp16 noise floor - the shared part runs
+        other tile shapes), the redundant half of that prefix is not recomputed.
         sample [Bs,C,T,h,w] (fp32 or storage dtype), cond [Bc,C,1,h,w], mask [Bm,1,1,h,w] | None, t fp32 [B], motion_t fp32 [B] |
-        None (or a ready [B, ch0] `cond_emb`), text_tokens [B*L, D]; returns [B*(T+1)*h*w, out_channels] tokens."""
+        None (or a ready [B, ch0] `cond_emb`), text_tokens [B*L, D]; returns the token matrix [B*(T+1)*h*w, 8]: columns [0, out_channels) are
+        conv_out's channels, the rest zero filters (`_conv_out_pack`) - consumers take the row pitch (`stride(0)`) or slice."""
         dt = text_tokens.dtype
         ch0 = self.conv_in.out_channels
         t_sin = ops.timestep_embedding(t, ch0, dt)                                       # :408-413

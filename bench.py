@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--no-tile-cache", action="store_true", help="ignore the committed tile choices (animate_anything_amd/tile_cache_gfx950.json): autotune everything")
     p.add_argument("--tile-cache", default="", help="json file with autotuned tile choices: loaded if present, written after warm-up")
     p.add_argument("--gemm-breakdown", default="", help="write a per-shape table of the contraction launches of one step")
+    p.add_argument("--launch-list", default="", help="run one more eager step and write its contraction calls IN LAUNCH ORDER (shape, kernel launches, "
+                                                     "algorithmic bytes) as json: what scripts/pmc_traffic_report.py joins the per-dispatch PMC rows with")
     p.add_argument("--workload", default="unet3d", choices=["unet3d", "svd", "rgba"],
                    help="unet3d: BASELINE configs[1] (the metric of record); svd: configs[3]; rgba: configs[4]")
     a = p.parse_args()
@@ -219,6 +221,36 @@ def contraction_roofline(trace, gemm_breakdown, flop_step, step_ms):
             "algorithmic_bytes_per_step": round(alg_bytes), "traffic_bytes_per_step": traffic_step,
             "traffic_over_algorithmic": round(traffic_step / alg_bytes, 3) if traffic_step else None,
             "whole_step_frac_of_peak": round(flop_step / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+
+
+def write_launch_list(path, unet, one_step):
+    """One eager step's aa_conv_gemm calls in launch order: per call the shape, how many contraction-kernel launches it makes (main launch +
+    split-off last round; generic-kernel and split-K reduce launches listed apart) and its algorithmic bytes (unique input + weights +
+    output (+ residual)) - the per-dispatch rows of a rocprofv3 PMC pass of the same command are joined with this list
+    (scripts/pmc_traffic_report.py: measured / algorithmic bytes PER SHAPE)."""
+    import ctypes as C
+    from animate_anything_amd import _lib
+    lib = _lib.get()
+    unet.enable_graph(False)
+    ops.TRACE = []
+    with torch.no_grad():
+        one_step()
+    trace, ops.TRACE = ops.TRACE, None
+    torch.cuda.synchronize()
+    rows = []
+    for d, _ in trace:
+        m = d.n_img * d.h_out * d.w_out
+        n_cols = d.n_out // 2 if d.geglu else d.n_out
+        k = d.kh * d.kw * (d.c0 + d.c1)
+        generic = int(bool((d.c0 + d.c1) % 64 or d.c0 % 64 or n_cols % 8 or d.out_dtype != d.dtype))
+        reduces = int(lib.aa_conv_gemm_reduce_launches(C.byref(d)))
+        rows.append({"M": m, "K": k, "N": d.n_out, "kind": f"{d.kh}x{d.kw}s{d.stride}", "geglu": int(bool(d.geglu)), "two_source": int(d.c1 != 0),
+                     "residual": int(bool(d.residual)), "ln_fold": int(bool(d.ln_stats)), "tile": int(d.tile), "k_splits": int(d.k_splits),
+                     "launches": int(lib.aa_conv_gemm_launch_count(C.byref(d))) - reduces - generic, "reduce_launches": reduces, "generic": generic,
+                     "algorithmic_bytes": 2 * (d.n_img * d.h_in * d.w_in * (d.c0 + d.c1) + d.n_out * k + m * n_cols + (m * n_cols if d.residual else 0)),
+                     "flop": 2.0 * m * k * d.n_out})
+    with open(path, "w") as f:
+        json.dump(rows, f)
 
 
 def pick_traffic_record(profiles_dir, lib_id, launches):
@@ -518,7 +550,8 @@ def bench(a, selftest=False):
         ops.load_tile_cache(a.tile_cache)
 
     # Headline = the STRICT step: both guidance halves run the whole UNet, as the reference does (44.262 TFLOP).  The product's
-    # default computes the text-independent prefix once per pair (identical latents, 1.64 TFLOP less): timed too, reported
+    # default computes the text-independent prefix once per pair (the same arithmetic, 1.64 TFLOP less; latents equal to the strict form
+    # within the fp16 noise floor, not bit for bit - `max_abs_latent_difference_after_2_steps` below): timed too, reported
     # separately as `cfg_shared_prefix` (or as the headline with --cfg-shared-prefix).
     pipe.cfg_shared_prefix = bool(a.cfg_shared_prefix)
 
@@ -615,6 +648,8 @@ def bench(a, selftest=False):
         if a.workload != "unet3d" or (a.frames, a.size, a.dtype) != (16, 512, "fp16"):      # the committed PMC run is of the default command
             out["roofline"]["traffic"] = out["roofline"]["traffic_bytes_per_step"] = out["roofline"]["traffic_over_algorithmic"] = None
     out["autotuned_signatures"] = int(ops.AUTOTUNE_EVENTS)      # 0 = every contraction signature came from the committed tile cache
+    if rank == 0 and a.launch_list:
+        write_launch_list(a.launch_list, unet, lambda: run(ts[:1], inp["latents"]))
     if pinned:
         out["cpu_affinity"] = f"{len(pinned)} CPUs of the GPU's NUMA node"
     if a.workload == "rgba" and rank == 0:

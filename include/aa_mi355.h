@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AA_VERSION 107
+#define AA_VERSION 108
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
@@ -253,6 +253,46 @@ typedef struct AaAttention {
 } AaAttention;
 
 int aa_attention(const AaAttention* d, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * aa_seq_self_attention (version 108): the front half of a self-attention sub-block over SHORT sequences as ONE kernel -
+ *     O = softmax(q k^T * scale) v      with      [q | k | v] = LayerNorm(x) [Wq | Wk | Wv]^T,      head_dim 64
+ * i.e. diffusers BasicTransformerBlock.norm1 / norm2 -> Attention.to_q / to_k / to_v -> F.scaled_dot_product_attention as
+ * TransformerTemporalModel runs them over the frames of one pixel (reference models/unet_3d_blocks.py:379,526,759,
+ * models/unet_3d_condition_mask.py:433-437; double_self_attention: both attention layers of the block).  Q, K and V are never
+ * written: the caller follows up with the output projection (aa_conv_gemm on `o`, + bias + residual).
+ * A sequence is (outer o, inner i) as in aa_attention: position p of sequence number n = o * n_inner + i is row
+ *     o * outer_stride + i * inner_stride + p * pos_stride
+ * of x ([rows][ldx]) and of o ([rows][ldo], columns [0, channels)); seq_len <= 32.
+ * `w` is packed by the host: [heads][3][64][channels] storage dtype - per head the 64 to_k rows, the 64 to_v rows in the order
+ * v(i) = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3) for packed row i of each 32-row half, then the 64 to_q rows; with `normalize` the
+ * LayerNorm's gamma is folded in (W' = W diag(gamma), rounded to the storage type) and its beta arrives as `w_bias` = W beta (fp32, the
+ * same packed row order; none of the three projections has a bias of its own in the reference): the kernel itself only normalises
+ * the rows, x~ = (x - mean) / sqrt(var + ln_eps) - the re-association aa_conv_gemm's folded LayerNorm uses (ln_cols).
+ * Supported (aa_seq_self_attention_ok): channels 320, 512 or 640 (what one wave can hold of x in registers), heads * 64 == channels.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct AaSeqSelfAttn {
+    const void* x;          /* [rows][ldx] storage dtype */
+    const void* w;          /* [channels / 64][3][64][channels] storage dtype */
+    const float* w_bias;    /* [channels / 64][3][64] fp32: what the projections start from (W beta of a folded LayerNorm), or NULL */
+    void* o;                /* [rows][ldo] storage dtype */
+    int64_t outer_stride, inner_stride, pos_stride;   /* in rows */
+    int64_t x_bytes, o_bytes;   /* extents of x and o the call may touch (each < 2 GiB: 32-bit offsets through buffer descriptors) */
+    int32_t n_outer, n_inner, seq_len;
+    int32_t channels;
+    int32_t ldx, ldo;       /* row pitches in elements, multiples of 8 */
+    int32_t normalize;      /* 1: rows of x are normalised to zero mean / unit variance (ln_eps) in front of the projections; 0: x as it is */
+    float ln_eps;
+    float scale;            /* head_dim ** -0.5 */
+    int32_t dtype;          /* AA_F16 | AA_BF16 */
+    int32_t flags;          /* 0 in production; timing ablations (results are garbage): 1 no attention phase, 2 no weight DMA behind the first
+                               two stages, 4 no projection MFMAs, 8 no x fetch / normalisation, 16 no output stores, 32 no normalisation */
+} AaSeqSelfAttn;
+
+/* 1 if aa_seq_self_attention carries out this call, 0 if the caller has to take the three-launch form (aa_conv_gemm on the
+ * concatenated Q|K|V rows, aa_attention) - looks at channels, seq_len, strides and extents only. */
+int aa_seq_self_attention_ok(const AaSeqSelfAttn* d);
+int aa_seq_self_attention(const AaSeqSelfAttn* d, void* stream);
 
 /* aa_softmax_rows: y[r, :] = softmax(x[r, :]) for fp32 scores (VAE mid-block single-head
  * attention, head_dim 512, where scores are materialised: diffusers Attention with

@@ -239,6 +239,7 @@ inline unsigned ones_pair(bf16_t) { return 0x3F803F80u; }
 inline long long clock_now() { static thread_local long long t = 0; return t += 64; }
 inline long long wall_now() { return clock_now(); }
 inline long long hw_id() { return 0; }
+inline void spin_wall_ticks(int) {}
 struct BufRsrc { const char* base; unsigned bytes; };
 inline BufRsrc make_rsrc(const void* base, unsigned bytes) { return BufRsrc{static_cast<const char*>(base), bytes}; }
 inline void async_copy16_buf(const BufRsrc& r, unsigned byte_offset, void* lds_wave_base) {
@@ -272,6 +273,8 @@ inline u32x2 lds_read_tr16_b64(const void* lds_ptr) {
 
 template <int N>
 inline void dma_wait() {}                       // the emulator's DMA is synchronous
+inline void mem_wait_all() {}
+inline void sched_fence() {}
 inline void block_barrier() { emu::block_barrier(); }
 inline void wave_sync() { emu::wave_barrier(); }
 

@@ -169,6 +169,62 @@ def test_reference_pipeline_call_equals_oracle_pipeline(ref_mod):
         assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
 
 
+def test_reference_pipeline_call_drives_the_product_modules(ref_mod, emu):
+    """The drop-in boundary itself (north star: "so train.py --eval still drives it"): the REFERENCE's `LatentToVideoPipeline.__call__`
+    (models/pipeline.py:12-214, unmodified, on the stub `TextToVideoSDPipeline` base) given the PRODUCT's `UNet3DConditionModel` (HIP
+    kernels on the SIMT emulator) and the PRODUCT's `DPMSolverMultistepScheduler` as its `unet` / `scheduler` attributes.  Every step's
+    latents must be (a) equal to the product's own loop over the same module interfaces (`_denoise_generic`) up to the fp16 rounding of the
+    guidance arithmetic - the reference combines the two halves in the UNet's dtype (`noise_pred_uncond + g * (text - uncond)` on fp16
+    tensors, pipeline.py:181-183), the product in fp32 -, (b) within fp16 tolerance of the product's fused loop (`denoise`: session +
+    guidance / solver kernel) and (c) within tolerance of the oracle loop."""
+    import oracle
+    import models.pipeline as P
+    from animate_anything_amd.pipeline import LatentToVideoPipeline as ProductPipeline
+    from animate_anything_amd.schedulers import DPMSolverMultistepScheduler as ProductScheduler
+    from animate_anything_amd.unet3d import UNet3DConditionModel as ProductUNet
+    assert P.__file__.startswith(REF)
+    torch.manual_seed(0)
+    orc = oracle.UNet3DConditionModel(**TINY_UNET).eval()
+    state = seeded_state(orc)
+    orc.load_state_dict(state)
+    net = ProductUNet(**TINY_UNET).eval()
+    net.load_state_dict(state, strict=True)
+    net = net.half()
+    g = torch.Generator().manual_seed(9)
+    r = lambda *s: torch.randn(*s, generator=g)
+    frames, h, w, steps = 3, 8, 8, 3
+    x0, noise, pos, neg = r(1, 4, 1, h, w) * 0.5, r(1, 4, frames, h, w), r(1, 7, 64), r(1, 7, 64)
+    mask = torch.zeros(1, 1, 1, h, w)
+    mask[..., 2:6, 2:6] = 1
+    osched = oracle.DPMSolverMultistepScheduler()
+    osched.set_timesteps(steps)
+    init = oracle.ddpm_add_noise(x0.repeat(1, 1, frames, 1, 1), noise, int(osched.timesteps[0]))
+    for guidance in (9.0, 1.0):
+        kw = dict(latents=init, prompt_embeds=pos.half(), negative_prompt_embeds=neg.half(), condition_latent=x0.half(), mask=mask.half(),
+                  motion=[4.0], num_inference_steps=steps, guidance_scale=guidance, return_dict=False)
+        seen_ref, seen_gen, seen_fused, seen_orc = [], [], [], []
+        ref_pipe = P.LatentToVideoPipeline(None, None, None, net, ProductScheduler())
+        ref_pipe.decode_latents = lambda lat: torch.zeros(1, 3, lat.shape[2], 8, 8)        # (no VAE in this test)
+        with torch.no_grad():
+            _, got = ref_pipe(height=h * 8, width=w * 8, output_type="pt", callback=lambda i, t, l: seen_ref.append(l.float().clone()), **kw)
+        # (a) the product's loop over the same module interfaces
+        gen = ProductPipeline(vae=None, unet=net, scheduler=ProductScheduler())
+        gen.denoise = gen._denoise_generic
+        gen(callback=lambda i, t, l: seen_gen.append(l.float().clone()), **kw)
+        # (b) the product's default loop (session + fused guidance / solver kernel)
+        ProductPipeline(vae=None, unet=net, scheduler=ProductScheduler())(callback=lambda i, t, l: seen_fused.append(l.float().clone()), **kw)
+        # (c) the oracle
+        okw = dict(kw, prompt_embeds=pos, negative_prompt_embeds=neg, condition_latent=x0, mask=mask)
+        oracle.LatentToVideoPipeline(None, orc, osched)(callback=lambda i, t, l: seen_orc.append(l.clone()), **okw)
+        assert len(seen_ref) == len(seen_gen) == len(seen_fused) == len(seen_orc) == steps
+        for a, b, c, d in zip(seen_ref, seen_gen, seen_fused, seen_orc):
+            scale = max(1.0, d.abs().max().item())
+            assert (a - b).abs().max().item() <= (2e-3 if guidance > 1.0 else 1e-6) * scale      # (no guidance: the same arithmetic, bit for bit up to fp32 round-off)
+            assert (a - c).abs().max().item() <= 1e-2 * scale
+            assert (a - d).abs().max().item() <= 3e-2 * scale
+        assert got.shape == init.shape
+
+
 def test_append_dims_and_offset_encoder_are_the_references(ref_mod):
     """`_append_dims` (models/pipeline.py:216-221) against the product's; `LatentTransparencyOffsetEncoder`
     (models/layerdiffuse_VAE.py:17-41, pure torch) against the oracle restatement on one state dict."""
