@@ -59,10 +59,18 @@ class AaAttention(C.Structure):
 
 class AaSeqSelfAttn(C.Structure):
     _fields_ = [
-        ("x", C.c_void_p), ("w", C.c_void_p), ("w_bias", C.c_void_p), ("o", C.c_void_p),
+        ("x", C.c_void_p), ("w", C.c_void_p), ("w_bias", C.c_void_p), ("pre_w", C.c_void_p), ("pre_bias", C.c_void_p), ("pre_residual", C.c_void_p), ("pre_out", C.c_void_p), ("o", C.c_void_p),
         ("outer_stride", C.c_int64), ("inner_stride", C.c_int64), ("pos_stride", C.c_int64), ("x_bytes", C.c_int64), ("o_bytes", C.c_int64),
-        ("n_outer", C.c_int32), ("n_inner", C.c_int32), ("seq_len", C.c_int32), ("channels", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32),
+        ("n_outer", C.c_int32), ("n_inner", C.c_int32), ("seq_len", C.c_int32), ("channels", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32), ("ld_res", C.c_int32), ("ld_pre", C.c_int32),
         ("normalize", C.c_int32), ("ln_eps", C.c_float), ("scale", C.c_float), ("dtype", C.c_int32), ("flags", C.c_int32),
+    ]
+
+
+class AaFFFused(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("outer", C.c_void_p), ("out", C.c_void_p), ("w", C.c_void_p), ("rows", C.c_int64),
+        ("channels", C.c_int32), ("ldx", C.c_int32), ("ld_outer", C.c_int32), ("ldo", C.c_int32),
+        ("normalize", C.c_int32), ("ln_eps", C.c_float), ("dtype", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -120,7 +128,7 @@ class AaEulerStepTok(C.Structure):
 
 
 SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_conv_gemm_row_stats_parts", "aa_conv_gemm_row_coef_ok", "aa_conv_gemm_tickets", "aa_conv_gemm_reduce_launches", "aa_conv_gemm_tile_flags", "aa_ln_finalize", "aa_groupnorm_workspace", "aa_groupnorm", "aa_set_groupnorm_two_pass", "aa_groupnorm_plan",
-           "aa_layernorm", "aa_attention", "aa_seq_self_attention_ok", "aa_seq_self_attention", "aa_softmax_rows", "aa_cfg_dpm_step",
+           "aa_layernorm", "aa_attention", "aa_seq_self_attention_ok", "aa_seq_self_attention", "aa_ff_fused_ok", "aa_ff_fused", "aa_softmax_rows", "aa_cfg_dpm_step",
            "aa_timestep_embedding", "aa_pack_latents", "aa_cfg_dpm_step_tokens",
            "aa_blend", "aa_pack_frames", "aa_cfg_euler_step_tokens")
 
@@ -169,6 +177,8 @@ def bind(path: str) -> C.CDLL:
     lib.aa_attention.argtypes = [C.POINTER(AaAttention), C.c_void_p]
     lib.aa_seq_self_attention_ok.argtypes = [C.POINTER(AaSeqSelfAttn)]
     lib.aa_seq_self_attention.argtypes = [C.POINTER(AaSeqSelfAttn), C.c_void_p]
+    lib.aa_ff_fused_ok.argtypes = [C.POINTER(AaFFFused)]
+    lib.aa_ff_fused.argtypes = [C.POINTER(AaFFFused), C.c_void_p]
     lib.aa_softmax_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.aa_cfg_dpm_step.argtypes = [C.POINTER(AaDpmStep), C.c_void_p]
     lib.aa_timestep_embedding.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]

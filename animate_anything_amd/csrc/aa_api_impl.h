@@ -15,6 +15,7 @@
 #include "kernels/norm.h"
 #include "kernels/attention.h"
 #include "kernels/seq_attention.h"
+#include "kernels/ff_fused.h"
 #include "kernels/glue.h"
 
 namespace aa {
@@ -520,6 +521,13 @@ static int attention_t(const AaAttention& d, void* stream) {
         while (qb > 1 && (int64_t)((n_qb + 4 * qb - 1) / (4 * qb)) * d.heads * nseq < 1024) qb >>= 1;
         const dim3 grid((n_qb + 4 * qb - 1) / (4 * qb), d.heads, nseq);
         AA_LAUNCH((attention_shortkv_kernel<T>), grid, dim3(256), 2 * AT_TILE_BYTES, stream, d, qb);
+    } else if (d.q_len >= 512 && d.kv_len >= 512 && (d._pad & 8)) {
+        // AaAttention._pad bit 3 (experiment, round 6): long sequences with two 32-query blocks per wave at two waves per SIMD.  Measured SLOWER
+        // than one block per wave at three waves per SIMD - 1058 against 883 us at 34 x 5 x 4096 tokens, 169 against 159 at 34 x 10 x 1024
+        // (profiles/r06g_attention_two_blocks_per_wave.txt): at 249 registers only two V^T fragment pairs can be in flight, every O^T MFMA
+        // waits for its LDS read, and two waves per SIMD do not cover that.  Kept for the tests that walk its slow path; never the default.
+        const dim3 grid((d.q_len + 255) / 256, d.heads, nseq);
+        AA_LAUNCH((attention_kernel<T, 4, 64, 1, 2>), grid, dim3(256), attn_lds_bytes(d.kv_len), stream, d);
     } else if (d.q_len > 64) {
         const dim3 grid((d.q_len + 127) / 128, d.heads, nseq);
         AA_LAUNCH((attention_kernel<T, 4>), grid, dim3(256), attn_lds_bytes(d.kv_len), stream, d);
@@ -784,6 +792,14 @@ int aa_seq_self_attention(const AaSeqSelfAttn* d, void* stream) {
     if (!aligned16(d->x) || !aligned16(d->w) || !aligned16(d->o) || !aligned16(d->w_bias))
         return fail(AA_E_ALIGN, "seq_self_attention: operands must be 16-byte aligned");
     if (d->normalize && !(d->ln_eps > 0.0f)) return fail(AA_E_SHAPE, "seq_self_attention: normalize needs ln_eps > 0");
+    if (d->pre_w) {
+        if (!d->pre_out || !aligned16(d->pre_w) || !aligned16(d->pre_out) || !aligned16(d->pre_bias) || !aligned16(d->pre_residual))
+            return fail(AA_E_ALIGN, "seq_self_attention: the projection in front needs pre_out and 16-byte aligned operands");
+        const int64_t rows_ext = d->x_bytes / (2 * (int64_t)d->ldx);
+        if (d->ld_pre % 8 || d->ld_pre < d->channels || rows_ext * d->ld_pre * 2 >= ((int64_t)1 << 31) ||
+            (d->pre_residual && (d->ld_res % 8 || d->ld_res < d->channels || rows_ext * d->ld_res * 2 >= ((int64_t)1 << 31))))
+            return fail(AA_E_SHAPE, "seq_self_attention: bad row pitch / extent of pre_out / pre_residual");
+    } else if (d->pre_bias || d->pre_residual || d->pre_out) return fail(AA_E_SHAPE, "seq_self_attention: pre_bias / pre_residual / pre_out without pre_w");
     const int per = (32 * SA_NW) / d->seq_len;
     const int64_t n_seq = (int64_t)d->n_outer * d->n_inner;
     const dim3 grid((unsigned)((n_seq + per - 1) / per)), block(64 * SA_NW);
@@ -796,6 +812,34 @@ int aa_seq_self_attention(const AaSeqSelfAttn* d, void* stream) {
     }
 #undef AA_SA
     return finish("seq_self_attention");
+}
+
+int aa_ff_fused_ok(const AaFFFused* d) {
+    if (!d || d->channels != 320 || d->rows <= 0) return 0;
+    if (d->ldx % 8 || d->ldo % 8 || d->ld_outer % 8 || d->ldx < d->channels || d->ldo < d->channels || (d->outer && d->ld_outer < d->channels)) return 0;
+    const int64_t lim = (int64_t)1 << 31;
+    if (d->rows * d->ldx * 2 >= lim || d->rows * d->ldo * 2 >= lim || (d->outer && d->rows * d->ld_outer * 2 >= lim)) return 0;
+    if (d->dtype != AA_F16 && d->dtype != AA_BF16) return 0;
+    return 1;
+}
+
+int aa_ff_fused(const AaFFFused* d, void* stream) {
+    using namespace aa;
+    if (!d) return fail(AA_E_SHAPE, "ff_fused: null descriptor");
+    if (!aa_ff_fused_ok(d)) return fail(AA_E_SHAPE, "ff_fused: unsupported call (channels %d, rows %lld, dtype %d)", d->channels, (long long)d->rows, d->dtype);
+    if (!d->x || !d->out || !d->w) return fail(AA_E_SHAPE, "ff_fused: x, out, w are required");
+    if (!aligned16(d->x) || !aligned16(d->outer) || !aligned16(d->out) || !aligned16(d->w)) return fail(AA_E_ALIGN, "ff_fused: operands must be 16-byte aligned");
+    if (d->normalize && !(d->ln_eps > 0.0f)) return fail(AA_E_SHAPE, "ff_fused: normalize needs ln_eps > 0");
+    const dim3 grid((unsigned)((d->rows + 32 * FF_NW - 1) / (32 * FF_NW))), block(64 * FF_NW);
+    const int abl = d->flags >> 8;             // timing ablations (scripts/bench_ff_fused.py --ablate): fp16 instantiations only
+#define AA_FF(ABL_) case ABL_: AA_LAUNCH((ff_fused_kernel<f16_t, 320, ABL_>), grid, block, ff_lds_bytes(), stream, *d); break
+    if (abl && d->dtype == AA_F16) {
+        switch (abl) { AA_FF(1); AA_FF(4); AA_FF(8); AA_FF(16); AA_FF(32); AA_FF(33); AA_FF(24); AA_FF(61); AA_FF(256); AA_FF(64); AA_FF(128);
+                       default: return fail(AA_E_SHAPE, "ff_fused: no instantiation for ablation %d", abl); }
+    } else if (d->dtype == AA_F16) AA_LAUNCH((ff_fused_kernel<f16_t, 320>), grid, block, ff_lds_bytes(), stream, *d);
+    else                    AA_LAUNCH((ff_fused_kernel<bf16_t, 320>), grid, block, ff_lds_bytes(), stream, *d);
+#undef AA_FF
+    return finish("ff_fused");
 }
 
 int aa_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int32_t x_ld, int32_t y_ld, int32_t dtype, void* stream) {

@@ -65,8 +65,15 @@ __host__ __device__ inline int64_t attn_extent_bytes(const AaAttnOperand& x, int
 // G > 1 (single-tile sequences only): a workgroup carries G INDEPENDENT sequences, one per wave, each with its own LDS tile - the
 // 17-frame temporal attention of the 64x64 level is 40960 one-wave sequences per call, and one-wave workgroups are launched
 // more slowly than they finish.
-template <typename T, int NW, int KT = 64, int G = 1>
-__global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) attention_kernel(const AaAttention p) {
+// QB = 32-query blocks per wave.  QB = 2 (round 6 experiment, AaAttention._pad bit 3, NOT the default - measured slower, see aa_api_impl.h):
+// a wave owns 64 queries at two waves per SIMD (256 registers).
+// Every K fragment feeds both blocks' S^T MFMAs (half the K reads per MFMA), and the blocks are worked ONE AFTER THE OTHER through
+// softmax and O^T: block 1's exponentials are issued behind block 0's O^T MFMAs and run while the matrix pipe executes them - with one
+// block per wave the pipe idles through every softmax unless another wave happens to be in its matrix phase (35 % busy at three waves
+// per SIMD, profiles/r05zz_pmc_step_sq.json).  Per tile and wave: 32 MFMAs for one barrier / DMA issue / loop pass instead of 16.
+template <typename T, int NW, int KT = 64, int G = 1, int QB = 1>
+__global__ void __launch_bounds__(64 * NW * G, QB == 2 ? 2 : (NW > 1 ? 3 : (KT == 32 ? 4 : 2))) attention_kernel(const AaAttention p) {
+    static_assert(QB == 1 || (QB == 2 && KT == 64 && NW == 4 && G == 1), "two query blocks per wave: the multi-tile kernel only");
     constexpr int PER = (KT / 4) / NW;           // DMA instructions per wave and tile (KT/8 for K + KT/8 for V in total)
     constexpr int KB = KT / 32;                  // 32-key blocks per tile
     constexpr int TILE_BYTES = 2 * KT * 128;
@@ -82,14 +89,15 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
     if (G > 1 && seq >= p.n_outer * p.n_inner) return;
     char* lds = dyn_smem() + (G > 1 ? wave_id() * TILE_BYTES : 0);
     const int o = seq / p.n_inner, i = seq - o * p.n_inner;
-    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int q0 = (blockIdx.x * NW + wave) * 32 * QB;
     const bool wave_active = q0 < p.q_len;
     const float sl2e = p.scale * 1.4426950408889634f;   // folded into Q: scores are in base-2 exponent units
 
     // Q fragment: B operand of S^T (col = query, k = d)
-    u32x4 qf[4];
-    {
-        const int q = q0 + ql;
+    u32x4 qf[QB][4];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int q = q0 + 32 * b + ql;
         const bool ok = q < p.q_len;
         const T* src = attn_row<T>(p.q, o, i, p.n_inner, ok ? q : 0, head) + 8 * h;
 #pragma unroll
@@ -99,7 +107,7 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
             if (ok) v.raw = *reinterpret_cast<const u32x4*>(src + 16 * dk);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.e[e] = (T)((float)v.e[e] * sl2e);      // scores come out in units of bits
-            qf[dk] = v.raw;
+            qf[b][dk] = v.raw;
         }
     }
 
@@ -143,13 +151,21 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
         }
     };
 
-    f32x16 oacc[2];
+    f32x16 oacc[QB][2];
+    float m_run[QB], l_run[QB];                 // running (lazily moved) max of the scaled scores, running sum of this half-wave's keys
+    // -m_run in every entry: the C operand that starts a score block.  QB == 2: the accumulators start at zero (an inline constant) and the
+    // maximum is subtracted in front of the exponential instead - two of these vectors are 32 registers the 64-query wave does not have
+    constexpr bool SUB_MAX = QB == 2;
+    f32x16 minus_m[SUB_MAX ? 1 : QB];
+    f32x16 zero16;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.0f; oacc[1][e] = 0.0f; }
-    float m_run = 0.0f, l_run = 0.0f;           // running (lazily moved) max of the scaled scores, running sum of this half-wave's keys
-    f32x16 minus_m;                             // -m_run in every entry: the C operand that starts a score block
+    for (int e = 0; e < 16; ++e) { zero16[e] = 0.0f; minus_m[0][e] = 0.0f; }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) minus_m[e] = 0.0f;
+    for (int b = 0; b < QB; ++b) {
+        m_run[b] = 0.0f; l_run[b] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { oacc[b][0][e] = 0.0f; oacc[b][1][e] = 0.0f; }
+    }
 
     const bool prio = (p._pad & 1) != 0;
     constexpr bool eager_max = AA_ATTN_EAGER_MAX != 0;
@@ -170,7 +186,7 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
             const char* sV = sK + KT * 128;
             // S^T - m: the accumulators START at minus the running maximum (zero for the first tile) - the first MFMA of every
             // block takes a register set that holds -m in all 16 entries as its C operand, so no accumulator is initialised per tile
-            f32x16 sacc[KB];
+            f32x16 sacc[QB][KB];
             auto scores = [&]() __attribute__((always_inline)) {
                 if (prio) wave_priority<1>();         // (experiment, AaAttention._pad bit 0: matrix clusters above the co-resident waves' softmax)
                 // the two 32-key blocks alternate so that consecutive MFMAs never wait on each other's accumulator
@@ -189,7 +205,8 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
                     constexpr int i = decltype(i_)::value, dk = i / KB, kb = i % KB;
                     constexpr int issued = (i + WK < NK) ? i + WK : NK;
                     lds_wait<issued - i - 1>(kf[i]);
-                    sacc[kb] = mfma_32x32x16(T(), kf[i], qf[dk], dk == 0 ? minus_m : sacc[kb]);
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) sacc[b][kb] = mfma_32x32x16(T(), kf[i], qf[b][dk], dk == 0 ? (SUB_MAX ? zero16 : minus_m[SUB_MAX ? 0 : b]) : sacc[b][kb]);
                     if constexpr (i + WK < NK) k_read(IntTag<i + WK>());
                 });
                 } else {
@@ -198,28 +215,34 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
 #pragma unroll
                         for (int kb = 0; kb < KB; ++kb) {
                             const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + kb * 4096 + kf_row + (((2 * dk + h) ^ kf_swz) << 4));
-                            sacc[kb] = mfma_32x32x16(T(), kf, qf[dk], dk == 0 ? minus_m : sacc[kb]);
+#pragma unroll
+                            for (int b = 0; b < QB; ++b) sacc[b][kb] = mfma_32x32x16(T(), kf, qf[b][dk], dk == 0 ? (SUB_MAX ? zero16 : minus_m[SUB_MAX ? 0 : b]) : sacc[b][kb]);
                         }
                 }
                 if (prio) wave_priority<0>();
                 if (p.causal && kt * KT + KT - 1 > q0) {     // causal: keys after the query's own position (tiles that reach past the wave's first query)
-                    const int qpos = q0 + ql;
 #pragma unroll
-                    for (int kb = 0; kb < KB; ++kb)
+                    for (int b = 0; b < QB; ++b) {
+                        const int qpos = q0 + 32 * b + ql;
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int key = kt * KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                            if (key > qpos) sacc[kb][e] = -1.0e30f;
-                        }
+                        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int key = kt * KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                                if (key > qpos) sacc[b][kb][e] = -1.0e30f;
+                            }
+                    }
                 }
                 if (ragged && kt == ntiles - 1) {           // mask the keys past kv_len (last tile only)
 #pragma unroll
-                    for (int kb = 0; kb < KB; ++kb)
+                    for (int b = 0; b < QB; ++b)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int key = kt * KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                            if (key >= p.kv_len) sacc[kb][e] = -1.0e30f;
-                        }
+                        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int key = kt * KT + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                                if (key >= p.kv_len) sacc[b][kb][e] = -1.0e30f;
+                            }
                 }
             };
             scores();
@@ -227,7 +250,7 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
             // first four before the softmax (they do not depend on it: their latency runs under it).  As important: NOT through the builtin - for
             // that hipcc emits s_waitcnt vmcnt(0) in front of the first read (the LDS it reads may alias what an in-flight LDS-DMA deposits), i.e.
             // every wave waited, once per tile, for the K / V tile it had just prefetched.
-            constexpr int NP = 4 * KB, WP = NP < 4 ? NP : 4;              // pairs: (chunk ch = pair / 2, d block db = pair % 2)
+            constexpr int NP = 4 * KB, WP = QB == 2 ? 2 : (NP < 4 ? NP : 4);              // pairs: (chunk ch = pair / 2, d block db = pair % 2); two ahead is what the 64-query wave has registers for
             u32x2 vlo[NP], vhi[NP];
             const char* const vbase = sV + vf_off;
             auto v_read = [&](auto i_) __attribute__((always_inline)) {
@@ -241,11 +264,11 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
             // softmax on its true row maximum); every later tile exponentiates against the running maximum straight away and looks
             // at its maximum only if the sums say it has to (below): ~24 of a tile's ~130 vector instructions - this kernel is bound
             // by them (32 quarter-rate v_exp_f32 + ~100 others per 16 MFMAs), not by the matrix pipe.
-            auto row_over = [&]() __attribute__((always_inline)) {
+            auto row_over = [&](int b_) __attribute__((always_inline)) {
                 float mx[2 * KB];
 #pragma unroll
                 for (int c = 0; c < 2 * KB; ++c) {
-                    const f32x16& a = sacc[c >> 1];
+                    const f32x16& a = sacc[b_][c >> 1];
                     const int b = 8 * (c & 1);
                     const float m0 = fmaxf(fmaxf(a[b], a[b + 1]), a[b + 2]);
                     const float m1 = fmaxf(fmaxf(a[b + 3], a[b + 4]), a[b + 5]);
@@ -253,29 +276,31 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
                 }
                 float mall = fmaxf(mx[0], mx[1]);
                 if constexpr (KB == 2) mall = fmaxf(fmaxf(mall, mx[2]), mx[3]);
-                return wave_max_halves(mall);
+                return wave_max_halves(mall) - (SUB_MAX ? m_run[b_] : 0.0f);          // (SUB_MAX: the accumulators hold the scores themselves)
             };
             // move the maximum by `delta` (>= 0 per row; the first tile: its true maximum): everything still at the old maximum - O,
             // l and this tile's scores - is rescaled exactly once
-            auto move_max = [&](const float delta, const bool first) __attribute__((always_inline)) {
-                m_run += delta;
+            auto move_max = [&](int b_, const float delta, const bool first) __attribute__((always_inline)) {
+                m_run[b_] += delta;
+                if constexpr (!SUB_MAX) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) minus_m[e] = -m_run;
+                    for (int e = 0; e < 16; ++e) minus_m[SUB_MAX ? 0 : b_][e] = -m_run[b_];
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
+                    for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) sacc[kb][e] -= delta;
+                        for (int e = 0; e < 16; ++e) sacc[b_][kb][e] -= delta;
+                }
                 if (!first) {
                     const float alpha = fast_exp2(-delta);
-                    l_run *= alpha;
+                    l_run[b_] *= alpha;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+                    for (int e = 0; e < 16; ++e) { oacc[b_][0][e] *= alpha; oacc[b_][1][e] *= alpha; }
                 }
             };
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            u32x4 pf[2 * KB];
+            u32x4 pf[QB][2 * KB];
             // p = 2^(score - m) for this lane's keys -> the P^T operand registers; returns their sum
-            auto exponentiate = [&]() __attribute__((always_inline)) {
+            auto exponentiate = [&](int b_) __attribute__((always_inline)) {
                 f32x2 ps2[2 * KB];                                                          // packed partial row sums
 #pragma unroll
                 for (int c = 0; c < 2 * KB; ++c) ps2[c] = f32x2{0.0f, 0.0f};
@@ -287,81 +312,122 @@ __global__ void __launch_bounds__(64 * NW * G, NW > 1 ? 3 : (KT == 32 ? 4 : 2)) 
 #pragma unroll
                         for (int e = 0; e < 8; e += 2) {
                             f32x2 pe;
-                            pe[0] = fast_exp2(sacc[kb][8 * c + e]);                  // one v_exp per score
-                            pe[1] = fast_exp2(sacc[kb][8 * c + e + 1]);
+                            pe[0] = fast_exp2(sacc[b_][kb][8 * c + e] - (SUB_MAX ? m_run[b_] : 0.0f));                  // one v_exp per score
+                            pe[1] = fast_exp2(sacc[b_][kb][8 * c + e + 1] - (SUB_MAX ? m_run[b_] : 0.0f));
                             ps2[2 * kb + c] += pe;
                             pk.e[e] = (T)pe[0];
                             pk.e[e + 1] = (T)pe[1];
                         }
-                        pf[2 * kb + c] = pk.raw;
+                        pf[b_][2 * kb + c] = pk.raw;
                     }
                 f32x2 pst = ps2[0] + ps2[1];
                 if constexpr (KB == 2) pst += ps2[2] + ps2[3];
                 return pst[0] + pst[1];
             };
             if constexpr (eager_max) {                  // (-DAA_ATTN_EAGER_MAX=1 build, A/B only: the round-2..4 form - every tile computes its maximum.  A RUN-time
-                const float over = row_over();          //  switch made hipcc spill 25-37 registers in every instance of this kernel: build.py's audit rejects that)
-                if (kt == 0 || wave_any(over > AT_DEFER)) move_max(kt == 0 ? over : fmaxf(over, 0.0f), kt == 0);
-            } else if (kt == 0) move_max(row_over(), true);
-            float psum = exponentiate();
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {          //  switch made hipcc spill 25-37 registers in every instance of this kernel: build.py's audit rejects that)
+                    const float over = row_over(b);
+                    if (kt == 0 || wave_any(over > AT_DEFER)) move_max(b, kt == 0 ? over : fmaxf(over, 0.0f), kt == 0);
+                }
+            } else if (kt == 0) {
+#pragma unroll
+                for (int b = 0; b < QB; ++b) move_max(b, row_over(b), true);
+            }
+            // O^T += V^T P^T for one query block: chunk ch = 16 keys; this half-wave's 8 k-slots are keys 16ch + 4h + {0..3} and
+            // 16ch + 8 + 4h + {0..3} (the order P^T's registers came out of the S^T accumulator layout)
+            auto pv = [&](auto b__, auto first_) __attribute__((always_inline)) {
+                constexpr int b_ = decltype(b__)::value;
+                constexpr bool reads_issued = decltype(first_)::value;      // (block 0: the first WP pairs were issued in front of the softmax)
+                if (prio) wave_priority<1>();
+                if constexpr (AT_ASYNC_FRAGS<KT>()) {
+                if constexpr (!reads_issued) static_for<WP>(v_read);
+                static_for<NP>([&](auto i_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(i_)::value, ch = i / 2, db = i % 2;
+                    constexpr int issued = (i + WP < NP) ? i + WP : NP;
+                    lds_wait2<2 * (issued - i - 1)>(vlo[i], vhi[i]);                 // this pair has landed; the younger ones stay in flight
+                    const u32x4 vf = {vlo[i][0], vlo[i][1], vhi[i][0], vhi[i][1]};
+                    oacc[b_][db] = mfma_32x32x16(T(), vf, pf[b_][ch], oacc[b_][db]);
+                    if constexpr (i + WP < NP) v_read(IntTag<i + WP>());
+                });
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < 2 * KB; ++ch)
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const char* base = sV + (2 * ch) * 1024 + db * 256 + vf_off;
+                            const u32x2 lo = lds_read_tr16_b64(base), hi = lds_read_tr16_b64(base + 1024);
+                            const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+                            oacc[b_][db] = mfma_32x32x16(T(), vf, pf[b_][ch], oacc[b_][db]);
+                        }
+                }
+                if (prio) wave_priority<0>();
+            };
             // Lazy maximum (defer-max, round 5 form): the running maximum has to move only when some p would leave the range the
             // deferral allows (p <= 2^AT_DEFER).  A lane's p's are non-negative, so "one of them exceeds 2^AT_DEFER" implies "their
             // sum does" (and an overflowed p makes the sum inf, a NaN fails the comparison): the sum - needed anyway - is the whole
             // check.  When it fires the tile is multiplied again and its scores are looked at after all; rows that are more than
             // a bit above their maximum move it (so a flat run of p ~ 2..64 cannot fire tile after tile) and the tile is exponentiated
             // again.  Rare: after the first tile has centred a row, later keys seldom beat it by 6 bits.
-            if (kt != 0 && !eager_max && wave_any(!(psum <= 64.0f))) {
+            float psum[QB];
+#pragma unroll
+            for (int b = 0; b < QB; ++b) psum[b] = 0.0f;
+            psum[0] = exponentiate(0);
+            bool redo = kt != 0 && !eager_max && wave_any(!(psum[0] <= 64.0f));
+            if constexpr (QB == 2) {
+                // One block after the other; block 1's exponentials are issued behind block 0's O^T MFMAs and run while the pipe executes them.
+                // The rare path keeps the block's scores (they are live up to here anyway, and at 256 registers there is room): nothing is
+                // multiplied again.
                 static_assert(AT_DEFER == 6.0f, "the sum test above is 2^AT_DEFER");
-                // (the scores are NOT kept alive across the test - 32 more live registers at the kernel's 168-register cap spilled
-                //  into the hot loop and cost the 4096-key kernel 55 %, r05e: the rare path multiplies the tile again, K is still in its slot)
-                scores();
-                const float over = row_over();
-                if (wave_any(over > 1.0f)) move_max(fmaxf(over, 0.0f), false);
-                psum = exponentiate();
-            }
-            l_run += psum;
-            // O^T += V^T P^T: chunk ch = 16 keys; this half-wave's 8 k-slots are keys 16ch + 4h + {0..3} and
-            // 16ch + 8 + 4h + {0..3} (the order P^T's registers came out of the S^T accumulator layout)
-            if (prio) wave_priority<1>();
-            if constexpr (AT_ASYNC_FRAGS<KT>()) {
-            static_for<NP>([&](auto i_) __attribute__((always_inline)) {
-                constexpr int i = decltype(i_)::value, ch = i / 2, db = i % 2;
-                constexpr int issued = (i + WP < NP) ? i + WP : NP;
-                lds_wait2<2 * (issued - i - 1)>(vlo[i], vhi[i]);                 // this pair has landed; the younger ones stay in flight
-                const u32x4 vf = {vlo[i][0], vlo[i][1], vhi[i][0], vhi[i][1]};
-                oacc[db] = mfma_32x32x16(T(), vf, pf[ch], oacc[db]);
-                if constexpr (i + WP < NP) v_read(IntTag<i + WP>());
-            });
+                if (redo) {
+                    const float over = row_over(0);
+                    if (wave_any(over > 1.0f)) move_max(0, fmaxf(over, 0.0f), false);
+                    psum[0] = exponentiate(0);
+                }
+                l_run[0] += psum[0];
+                pv(IntTag<0>(), BoolTag<true>());
+                psum[1] = exponentiate(1);
+                if (kt != 0 && !eager_max && wave_any(!(psum[1] <= 64.0f))) {
+                    const float over = row_over(1);
+                    if (wave_any(over > 1.0f)) move_max(1, fmaxf(over, 0.0f), false);
+                    psum[1] = exponentiate(1);
+                }
+                l_run[1] += psum[1];
+                pv(IntTag<1>(), BoolTag<false>());
             } else {
-#pragma unroll
-                for (int ch = 0; ch < 2 * KB; ++ch)
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        const char* base = sV + (2 * ch) * 1024 + db * 256 + vf_off;
-                        const u32x2 lo = lds_read_tr16_b64(base), hi = lds_read_tr16_b64(base + 1024);
-                        const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
-                        oacc[db] = mfma_32x32x16(T(), vf, pf[ch], oacc[db]);
-                    }
+                if (redo) {
+                    static_assert(AT_DEFER == 6.0f, "the sum test above is 2^AT_DEFER");
+                    // (the scores are NOT kept alive across the test - 32 more live registers at the kernel's 168-register cap spilled
+                    //  into the hot loop and cost the 4096-key kernel 55 %, r05e: the rare path multiplies the tile again, K is still in its slot)
+                    scores();
+                    const float over = row_over(0);
+                    if (wave_any(over > 1.0f)) move_max(0, fmaxf(over, 0.0f), false);
+                    psum[0] = exponentiate(0);
+                }
+                l_run[0] += psum[0];
+                pv(IntTag<0>(), BoolTag<true>());
             }
-            if (prio) wave_priority<0>();
         }
     }
 
     if (wave_active) {
-        const float l_tot = wave_sum_halves(l_run);
-        const float inv = 1.0f / l_tot;
-        const int q = q0 + ql;
-        if (q < p.q_len) {
-            T* dst = const_cast<T*>(attn_row<T>(p.o, o, i, p.n_inner, q, head));
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+        for (int b = 0; b < QB; ++b) {
+            const float l_tot = wave_sum_halves(l_run[b]);
+            const float inv = 1.0f / l_tot;
+            const int q = q0 + 32 * b + ql;
+            if (q < p.q_len) {
+                T* dst = const_cast<T*>(attn_row<T>(p.o, o, i, p.n_inner, q, head));
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    union { u32x2 raw; T e[4]; } pk;
+                for (int db = 0; db < 2; ++db)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk.e[e] = (T)(oacc[db][4 * g + e] * inv);
-                    *reinterpret_cast<u32x2*>(dst + 32 * db + 8 * g + 4 * h) = pk.raw;
-                }
+                    for (int g = 0; g < 4; ++g) {
+                        union { u32x2 raw; T e[4]; } pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk.e[e] = (T)(oacc[b][db][4 * g + e] * inv);
+                        *reinterpret_cast<u32x2*>(dst + 32 * db + 8 * g + 4 * h) = pk.raw;
+                    }
+            }
         }
     }
 }

@@ -98,27 +98,167 @@ __global__ void __launch_bounds__(64 * SA_NW, PER_CU) seq_self_attention_kernel(
         const int slot = (lane % SPR) ^ ((row / RPB) & (SPR - 1));
         w_lane[j] = (unsigned)((row * C + kc * KC + slot * 8) * 2);
     }
-    auto issue = [&](int q, int buf) __attribute__((always_inline)) {            // stage q = (head, pass, sub): q = (head * 3 + pass) * SPP + sub
-        const int hp = q / SPP, sub = q - hp * SPP;
+    // Stages: first the NPRE stages of the projection in front (pre_w: C / 64 passes of 64 rows), then per head the K, V and Q passes.
+    constexpr int NQH = H * 3 * SPP;
+    const bool has_pre = p.pre_w != nullptr;
+    const int NPRE = has_pre ? (C / 64) * SPP : 0;
+    const int NQ = NPRE + NQH;
+    const BufRsrc r_pw = make_rsrc(p.pre_w, has_pre ? (unsigned)((int64_t)C * C * 2) : 0u);
+    auto issue = [&](int q, int buf) __attribute__((always_inline)) {            // stage q: pass q / SPP of its stream ((head * 3 + pass) of the main one), K range q % SPP
+        const bool pre = q < NPRE;
+        const int qq = pre ? q : q - NPRE;
+        const int hp = qq / SPP, sub = qq - hp * SPP;
         const unsigned uni = (unsigned)((hp * 64 * C + sub * SC * KC) * 2);
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int pi = wave + NW * j;
-            async_copy16_buf_s(r_w, w_lane[j], uni, ring + buf * STAGE_BYTES + (pi / PPC) * CHUNK_BYTES + (pi % PPC) * 1024);
+            async_copy16_buf_s(pre ? r_pw : r_w, w_lane[j], uni, ring + buf * STAGE_BYTES + (pi / PPC) * CHUNK_BYTES + (pi % PPC) * 1024);
         }
     };
-    constexpr int NQ = H * 3 * SPP;
     // AaSeqSelfAttn.flags: timing ablations (results are garbage): 1 no attention phase, 2 no weight DMA behind the first two stages, 4 no projection
     // MFMAs, 8 no x fetch / LayerNorm, 16 no output stores, 32 no row normalisation
     const int dbg = p.flags;
     issue(0, 0);
 
-    // ---- x fragments (B operand of the transposed products, A operand of the straight one): k-slice ks = 2 nb + s
-    u32x4 xf[NKS];
+    u32x4 xf[NKS];          // x fragments (B operand of the transposed products, A operand of the straight one): k-slice ks = 2 nb + s
+    // waves behind the tile's last row do no matrix work; their operand slots must hold finite values (p = 0 times V)
+    if (!wave_live) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<u32x4*>(xch + wave * 8192 + u * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // ---- weight fragment addresses: row c (+ 32 j) of a chunk, slot (4 nbl + 2 h + s) ^ swizzle(c): one register per k-slice (nbl, s) of a chunk
+    unsigned wa[SPC];
+#pragma unroll
+    for (int v = 0; v < SPC; ++v) wa[v] = (unsigned)(c * RB + ((((v >> 1) * 4 + 2 * h + (v & 1)) ^ ((c / RPB) & (SPR - 1))) << 4));
+
+    const float sl2e = p.scale * 1.4426950408889634f;
+    f32x16 zero16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.0f;
+
+    f32x16 acc[2];
+    // one stage: SC chunks = SPC SC k-slices, two MFMAs each; the fragment reads of slice u + 1 are in flight under the MFMAs of slice u
+    auto stage = [&](auto pass_, auto sub_, const char* st, const u32x4 (&xop)[NKS]) __attribute__((always_inline)) {
+        constexpr int pass = decltype(pass_)::value, sub = decltype(sub_)::value;
+        constexpr int NU = SPC * SC;
+        u32x4 wf[3][2];             // fragment reads run two k-slices ahead of the MFMAs (three register sets)
+        const char* b4[SPC];
+#pragma unroll
+        for (int v = 0; v < SPC; ++v) b4[v] = st + wa[v];
+        auto rd = [&](auto u_) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_)::value, kc = u / SPC, v = u % SPC, set = u % 3;
+            lds_read16_async_off<kc * CHUNK_BYTES>(wf[set][0], b4[v]);
+            lds_read16_async_off<kc * CHUNK_BYTES + 32 * RB>(wf[set][1], b4[v]);
+        };
+        rd(IntTag<0>());
+        if constexpr (NU > 1) rd(IntTag<1>());
+        static_for<NU>([&](auto u_) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_)::value, set = u % 3, ks = sub * SC * SPC + u;
+            if constexpr (u + 2 < NU) { rd(IntTag<u + 2>()); lds_wait<4>(wf[set][0]); }
+            else if constexpr (u + 1 < NU) lds_wait<2>(wf[set][0]);
+            else lds_wait<0>(wf[set][0]);
+            lds_pin(wf[set][1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (pass == 1) acc[j] = mfma_32x32x16(T(), xop[ks], wf[set][j], acc[j]);     // V[token][d]
+                else                     acc[j] = mfma_32x32x16(T(), wf[set][j], xop[ks], acc[j]);     // K^T / Q^T [d][token]
+            }
+        });
+    };
+    // A pass's bias (W beta of the folded LayerNorm: `w_bias`; the bias of the projection in front: `pre_bias`; fp32, packed row order) is
+    // FETCHED at the top of the pass and ADDED behind it: starting the accumulators from it put an L2 round trip in front of the first MFMA
+    // of every pass (15 per tile: the "barriers and loops only" ablation of r06f took 41 us).  Transposed passes (K, Q, projection in front):
+    // register r of block j is packed row 32 j + (r & 3) + 8 (r >> 2) + 4 h - four 16-byte loads per block; straight pass (V): the lane's
+    // column 32 j + c in every register.
+    f32x16 pbias[2];
+    auto fetch_bias = [&](auto pass_, const float* b) __attribute__((always_inline)) {
+        constexpr int pass = decltype(pass_)::value;
+        acc[0] = zero16; acc[1] = zero16;
+        if (b == nullptr) { pbias[0] = zero16; pbias[1] = zero16; return; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (pass == 1) {
+                const float v = b[32 * j + c];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pbias[j][e] = v;
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(b + 32 * j + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pbias[j][4 * g4 + e] = v[e];
+                }
+            }
+        }
+    };
+    // the accumulators of a pass as operand registers: slice 2 j + t = registers 8 t .. 8 t + 7 of block j, rounded to the storage type
+    auto to_operands = [&](u32x4 (&op)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                Pack8<T> v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.e[e] = (T)(acc[j][8 * t + e] + pbias[j][8 * t + e]);
+                op[2 * j + t] = v.raw;
+            }
+    };
+
+    // ---- x: fetched once, straight into operand layout.  With a projection in front (pre_w) the fetched rows are ITS input; it runs here as
+    // C / 64 transposed passes of 64 output channels - lane (token, h) of block j then holds channels 64 pp + 32 j + 16 h .. + 15 (the rows of
+    // pre_w are packed in that order), exactly the k-slices 2 (2 pp + j), + 1 of the operand layout - plus the residual;
+    // the result x' is stored (pre_out) and attended over.
+    int q = 0;
     {
         const unsigned xb = (row_ok && !(dbg & 8)) ? (unsigned)(trow * p.ldx * 2) + (unsigned)(16 * h * 2) : OOB;
+        if (has_pre) {
+            u32x4 xin[NKS];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) xf[ks] = buf_load16(r_x, xb + (unsigned)((32 * (ks >> 1) + 8 * (ks & 1)) * 2));
+            for (int ks = 0; ks < NKS; ++ks) xin[ks] = buf_load16(r_x, xb + (unsigned)((32 * (ks >> 1) + 8 * (ks & 1)) * 2));
+            const int64_t rows_ext = p.x_bytes / (2 * (int64_t)p.ldx);
+            const BufRsrc r_res = make_rsrc(p.pre_residual, p.pre_residual ? (unsigned)(rows_ext * p.ld_res * 2) : 0u);
+            const BufRsrc r_po = make_rsrc(p.pre_out, (unsigned)(rows_ext * p.ld_pre * 2));
+            const unsigned rb = (row_ok && p.pre_residual) ? (unsigned)(trow * p.ld_res * 2) + (unsigned)(16 * h * 2) : OOB;
+            const unsigned pb = (row_ok && !(dbg & 16)) ? (unsigned)(trow * p.ld_pre * 2) + (unsigned)(16 * h * 2) : OOB;
+            static_for<C / 64>([&](auto pp_) __attribute__((always_inline)) {
+                constexpr int pp = decltype(pp_)::value;
+                u32x4 res[4];
+                static_for<SPP>([&](auto sub_) __attribute__((always_inline)) {
+                    // (the first stage of a later pass: its pieces were waited for in front of the previous pass's stores, see below)
+                    if (sub_.value == 0 && pp > 0) lds_wait_all(); else mem_wait_all();
+                    block_barrier();
+                    if (q + 1 < NQ && !((dbg & 2) && q >= 1)) issue(q + 1, (q + 1) & 1);
+                    if constexpr (sub_.value == 0) fetch_bias(IntTag<0>(), p.pre_bias ? p.pre_bias + pp * 64 : nullptr);
+                    if constexpr (sub_.value == SPP - 1) {          // the residual under this pass's 64 channels travels while its last stage multiplies (no residual: zeros)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) res[u] = buf_load16(r_res, rb + (unsigned)((64 * pp + 32 * (u >> 1) + 8 * (u & 1)) * 2));
+                    }
+                    if (wave_live && !(dbg & 4)) stage(IntTag<0>(), sub_, ring + (q & 1) * STAGE_BYTES, xin);
+                    ++q;
+                });
+                // x' of this pass's 64 channels: + residual, rounded, stored.  It is NOT kept: x (80 registers) and x' (80) side by side left the
+                // multiply stages no room (hipcc spilled ~100 registers, fetching the residual through scratch one load at a time) - the tile's
+                // x' is read back from L2 behind the last pass.
+                dma_wait<0>();          // the residual - and the next stage's weight pieces (issued a stage ago): only the stores below stay outstanding
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        Pack8<T> v; v.raw = res[2 * j + t];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v.e[e] = (T)(acc[j][8 * t + e] + pbias[j][8 * t + e] + (float)v.e[e]);
+                        buf_store16(r_po, pb + (unsigned)((64 * pp + 32 * j + 8 * t) * 2), v.raw);
+                    }
+            });
+            dma_wait<0>();              // my stores have reached L2 (nobody else wrote or cached these rows): read the tile's x' back
+            const unsigned pl = row_ok ? (unsigned)(trow * p.ld_pre * 2) + (unsigned)(16 * h * 2) : OOB;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) xf[ks] = buf_load16(r_po, pl + (unsigned)((32 * (ks >> 1) + 8 * (ks & 1)) * 2));
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) xf[ks] = buf_load16(r_x, xb + (unsigned)((32 * (ks >> 1) + 8 * (ks & 1)) * 2));
+        }
     }
     if (p.normalize && !(dbg & (8 | 32))) {
         // Row normalisation of nn.LayerNorm (fp32 statistics, biased variance; diffusers BasicTransformerBlock.norm1 / norm2): x~ = (x - mean) * rstd,
@@ -158,86 +298,6 @@ __global__ void __launch_bounds__(64 * SA_NW, PER_CU) seq_self_attention_kernel(
             xf[ks] = v.raw;
         }
     }
-    // waves behind the tile's last row do no matrix work; their operand slots must hold finite values (p = 0 times V)
-    if (!wave_live) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) *reinterpret_cast<u32x4*>(xch + wave * 8192 + u * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
-    }
-
-    // ---- weight fragment addresses: row c (+ 32 j) of a chunk, slot (4 nbl + 2 h + s) ^ swizzle(c): one register per k-slice (nbl, s) of a chunk
-    unsigned wa[SPC];
-#pragma unroll
-    for (int v = 0; v < SPC; ++v) wa[v] = (unsigned)(c * RB + ((((v >> 1) * 4 + 2 * h + (v & 1)) ^ ((c / RPB) & (SPR - 1))) << 4));
-
-    const float sl2e = p.scale * 1.4426950408889634f;
-    f32x16 zero16;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) zero16[e] = 0.0f;
-
-    f32x16 acc[2];
-    // one stage: SC chunks = SPC SC k-slices, two MFMAs each; the fragment reads of slice u + 1 are in flight under the MFMAs of slice u
-    auto stage = [&](auto pass_, auto sub_, const char* st) __attribute__((always_inline)) {
-        constexpr int pass = decltype(pass_)::value, sub = decltype(sub_)::value;
-        constexpr int NU = SPC * SC;
-        u32x4 wf[2][2];
-        const char* b4[SPC];
-#pragma unroll
-        for (int v = 0; v < SPC; ++v) b4[v] = st + wa[v];
-        auto rd = [&](auto u_) __attribute__((always_inline)) {
-            constexpr int u = decltype(u_)::value, kc = u / SPC, v = u % SPC, set = u & 1;
-            lds_read16_async_off<kc * CHUNK_BYTES>(wf[set][0], b4[v]);
-            lds_read16_async_off<kc * CHUNK_BYTES + 32 * RB>(wf[set][1], b4[v]);
-        };
-        rd(IntTag<0>());
-        static_for<NU>([&](auto u_) __attribute__((always_inline)) {
-            constexpr int u = decltype(u_)::value, set = u & 1, ks = sub * SC * SPC + u;
-            if constexpr (u + 1 < NU) { rd(IntTag<u + 1>()); lds_wait<2>(wf[set][0]); }
-            else lds_wait<0>(wf[set][0]);
-            lds_pin(wf[set][1]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if constexpr (pass == 1) acc[j] = mfma_32x32x16(T(), xf[ks], wf[set][j], acc[j]);     // V[token][d]
-                else                     acc[j] = mfma_32x32x16(T(), wf[set][j], xf[ks], acc[j]);     // K^T / Q^T [d][token]
-            }
-        });
-    };
-    // A pass starts from its bias W beta (`w_bias`, fp32, packed row order; zeros without it).  Transposed passes (K, Q): register r of
-    // block j is packed row 32 j + (r & 3) + 8 (r >> 2) + 4 h - four 16-byte loads per block; straight pass (V): the lane's column
-    // 32 j + c in every register.
-    auto start_acc = [&](auto pass_, int head) __attribute__((always_inline)) {
-        constexpr int pass = decltype(pass_)::value;
-        if (p.w_bias == nullptr) { acc[0] = zero16; acc[1] = zero16; return; }
-        const float* b = p.w_bias + (head * 3 + pass) * 64;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if constexpr (pass == 1) {
-                const float v = b[32 * j + c];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[j][e] = v;
-            } else {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(b + 32 * j + 8 * g4 + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[j][4 * g4 + e] = v[e];
-                }
-            }
-        }
-    };
-    // the accumulators of a pass as operand registers: slice 2 j + t = registers 8 t .. 8 t + 7 of block j, rounded to the storage type
-    auto to_operands = [&](u32x4 (&op)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                Pack8<T> v;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v.e[e] = (T)acc[j][8 * t + e];
-                op[2 * j + t] = v.raw;
-            }
-    };
-
-    int q = 0;
     for (int head = 0; head < H; ++head) {
         u32x4 qop[4];
         static_for<3>([&](auto pass_) __attribute__((always_inline)) {
@@ -245,11 +305,11 @@ __global__ void __launch_bounds__(64 * SA_NW, PER_CU) seq_self_attention_kernel(
             static_for<SPP>([&](auto sub_) __attribute__((always_inline)) {
                 // my pieces of stage q have landed, my operand slots are written.  (The first stage of a later head: its pieces were waited
                 // for in front of the previous head's output stores - those stay in flight across this barrier instead of being drained here)
-                if (pass == 0 && sub_.value == 0 && head > 0) lds_wait_all(); else mem_wait_all();
+                if (pass == 0 && sub_.value == 0 && (head > 0 || has_pre)) lds_wait_all(); else mem_wait_all();
                 block_barrier();                     // everyone's have; every wave is done with stage q - 1 and with the operand slots of the previous head
                 if (q + 1 < NQ && !((dbg & 2) && q >= 1)) issue(q + 1, (q + 1) & 1);
-                if constexpr (sub_.value == 0) start_acc(pass_, head);
-                if (wave_live && !(dbg & 4)) stage(pass_, sub_, ring + (q & 1) * STAGE_BYTES);
+                if constexpr (sub_.value == 0) fetch_bias(pass_, p.w_bias ? p.w_bias + (head * 3 + pass) * 64 : nullptr);
+                if (wave_live && !(dbg & 4)) stage(pass_, sub_, ring + (q & 1) * STAGE_BYTES, xf);
                 ++q;
             });
             if (wave_live) {
@@ -264,23 +324,36 @@ __global__ void __launch_bounds__(64 * SA_NW, PER_CU) seq_self_attention_kernel(
         if (!wave_live || (dbg & 1)) { dma_wait<0>(); continue; }
         // (every wave wrote its K operands before the barrier of the V pass and its V^T operands before the barrier of the Q pass)
         // ---- S^T = K Q^T against the row blocks wave-1, wave, wave+1
+        // (all twelve fragment reads go out at once - a block that does not exist reads a neighbour's slot and is not multiplied - and are
+        //  consumed block by block behind counted waits: one LDS latency per head instead of three)
         f32x16 sacc[3];
+        bool have[3];
+        const char* xslot[3];
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const int kb = wave - 1 + n;
+            have[n] = kb >= 0 && kb < NW && 32 * kb < rows_valid;
+            xslot[n] = xch + (have[n] ? kb : wave) * 8192 + lane * 16;
             sacc[n] = zero16;
-            if (kb >= 0 && 32 * kb < rows_valid && kb < NW) {
-                const char* kx = xch + kb * 8192 + lane * 16;
-                u32x4 kf[4];
-                lds_read16_async_off<0>(kf[0], kx);
-                lds_read16_async_off<1024>(kf[1], kx);
-                lds_read16_async_off<2048>(kf[2], kx);
-                lds_read16_async_off<3072>(kf[3], kx);
-                lds_wait<0>(kf[0]);
-                lds_pin(kf[1]); lds_pin(kf[2]); lds_pin(kf[3]);
+        }
+        {
+            u32x4 kf[3][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) sacc[n] = mfma_32x32x16(T(), kf[u], qop[u], sacc[n]);
+            for (int n = 0; n < 3; ++n) {
+                lds_read16_async_off<0>(kf[n][0], xslot[n]);
+                lds_read16_async_off<1024>(kf[n][1], xslot[n]);
+                lds_read16_async_off<2048>(kf[n][2], xslot[n]);
+                lds_read16_async_off<3072>(kf[n][3], xslot[n]);
             }
+            static_for<3>([&](auto n_) __attribute__((always_inline)) {
+                constexpr int n = decltype(n_)::value;
+                lds_wait<4 * (2 - n)>(kf[n][0]);
+                lds_pin(kf[n][1]); lds_pin(kf[n][2]); lds_pin(kf[n][3]);
+                if (have[n]) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sacc[n] = mfma_32x32x16(T(), kf[n][u], qop[u], sacc[n]);
+                }
+            });
         }
         // ---- softmax over the keys of the lane's own sequence (base 2, one pass).  L <= 32: the sequence lies in this block and ONE of its
         // neighbours - per lane the other neighbour's 16 scores are dropped before the exponentials (32 instead of 48 per lane)
@@ -320,23 +393,26 @@ __global__ void __launch_bounds__(64 * SA_NW, PER_CU) seq_self_attention_kernel(
         // ---- O^T = V^T P^T
         f32x16 oacc[2];
         oacc[0] = zero16; oacc[1] = zero16;
+        {
+            u32x4 vf[3][4];
 #pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const int kb = wave - 1 + n;
-            if (kb >= 0 && 32 * kb < rows_valid && kb < NW) {
-                const char* vx = xch + kb * 8192 + 4096 + lane * 16;
-                u32x4 vf[4];
-                lds_read16_async_off<0>(vf[0], vx);
-                lds_read16_async_off<1024>(vf[1], vx);
-                lds_read16_async_off<2048>(vf[2], vx);
-                lds_read16_async_off<3072>(vf[3], vx);
-                lds_wait<0>(vf[0]);
-                lds_pin(vf[1]); lds_pin(vf[2]); lds_pin(vf[3]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) oacc[j] = mfma_32x32x16(T(), vf[2 * j + t], pop[n][t], oacc[j]);
+            for (int n = 0; n < 3; ++n) {
+                lds_read16_async_off<4096>(vf[n][0], xslot[n]);
+                lds_read16_async_off<4096 + 1024>(vf[n][1], xslot[n]);
+                lds_read16_async_off<4096 + 2048>(vf[n][2], xslot[n]);
+                lds_read16_async_off<4096 + 3072>(vf[n][3], xslot[n]);
             }
+            static_for<3>([&](auto n_) __attribute__((always_inline)) {
+                constexpr int n = decltype(n_)::value;
+                lds_wait<4 * (2 - n)>(vf[n][0]);
+                lds_pin(vf[n][1]); lds_pin(vf[n][2]); lds_pin(vf[n][3]);
+                if (have[n]) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) oacc[j] = mfma_32x32x16(T(), vf[n][2 * j + t], pop[n][t], oacc[j]);
+                }
+            });
         }
         dma_wait<0>();                  // the next stage's weight pieces (issued a stage ago) - from here on only the stores below are outstanding
         // ---- lane (token c, h): channels head * 64 + 32 j + 16 h .. + 15 (the to_v rows were permuted for this at pack time)

@@ -92,6 +92,15 @@ SEQ_ATTN = os.environ.get("AA_SEQ_ATTN", "1") == "1"
 # ... where it is faster than the three launches: 320 channels (two workgroups per CU: 135-160 us against 262-278 at the 64x64 level) and 512
 # (transformer_in: 347-384 against 491-518); at 640 channels (32x32 level) x takes 160 registers, one workgroup per CU is left and 293 tiles
 # make two rounds of 256: 194-211 us against 163-174 (profiles/r06b_seq_attention_two_per_cu.txt) - the three launches stay there
+# ... and the linear layer in front of such an attention layer inside the same kernel (ops.seq_self_attention(pre=...)): proj_in in front of
+# the first one, the first one's to_out + residual in front of the second (AA_SEQ_PRE=0: separate contractions)
+SEQ_PRE = os.environ.get("AA_SEQ_PRE", "0") == "1"   # measured (r06f): 214 us against 151 + 79 apart in isolation, but +0.1 ms on the step - off
+# FeedForward + proj_out of a transformer as ONE kernel where the library has it (320 channels: the 64x64 level): ops.ff_fused instead of the GEGLU
+# contraction + the merged ff-out / proj_out contraction - the [tokens, 4 C] activation is never written (AA_FF_FUSED=0: the two contractions).
+# AA_FF_SPLIT=1: rows beyond the last FULL round of 128-row tiles over the chip's CUs (1088 tiles on 256 CUs = 4.25 rounds at the 64x64 level:
+# the fifth round runs 25 % full) go through the two contractions instead.
+FF_FUSED = os.environ.get("AA_FF_FUSED", "1") == "1"
+FF_SPLIT = os.environ.get("AA_FF_SPLIT", "1") == "1"
 SEQ_ATTN_CHANNELS = tuple(int(c) for c in os.environ.get("AA_SEQ_ATTN_CHANNELS", "320,512").split(",") if c)
 UPSAMPLE_AS_PARITY_CONVS = True      # Upsample2D at exactly x2: four 2x2 convolutions (ops.pack_upsample2x_weights); False = the 3x3 gather form
 
@@ -101,8 +110,22 @@ def _no_eager(name):
 
 
 class Linear(_Packed, nn.Linear):
+    _sp = None
+    _sp_key = None
+
     def tokens(self, x, **epilogue):
         return ops.conv_gemm(x, self.packed(), ops.linear_geom(x.shape[0]), **epilogue)
+
+    def seq_pre(self):
+        """This layer as the projection run inside ops.seq_self_attention in front of the normalisation (ops.pack_seq_pre), cached."""
+        key = weights_key(self.weight, self.bias)
+        if self._sp is None or self._sp_key != key:
+            self._sp, self._sp_key = ops.pack_seq_pre(self.weight, self.bias), key
+        return self._sp
+
+    def _apply(self, fn, *a, **k):
+        self._sp = None
+        return super()._apply(fn, *a, **k)
 
     def forward(self, x):
         _no_eager("Linear")
@@ -332,6 +355,12 @@ class Attention(nn.Module):
         return (SEQ_ATTN and temporal and not self.is_cross and self.dim_head == 64 and self.inner == x.shape[1] == self.to_q.in_features
                 and self.inner in SEQ_ATTN_CHANNELS and self.to_q.bias is None and ops.seq_self_attention_ok(self.inner, g.frames, x.shape[0], x.dtype))
 
+    def seq_attention(self, x, norm, g: "Grid", pre=None, residual=None):
+        """softmax(q k^T) v over the frames of each pixel with [q | k | v] = norm(x') W^T, x' = x (or pre(x) + residual) - one kernel, the
+        output projection NOT included.  Returns o, or (o, x') with `pre` (a Linear)."""
+        return ops.seq_self_attention(x, self.seq_packed(norm), g.clips, g.hw, g.frames, (g.frames * g.hw, 1, g.hw), scale=float(self.dim_head) ** -0.5,
+                                      pre=None if pre is None else pre.seq_pre(), residual=residual)
+
     def text_kv(self, text_tokens):
         """[clips*L, cross_dim] -> [clips*L, 2*inner] (K | V): normally a column slice of ONE projection of the text for
         all cross-attention layers of the network (`kv` set by the UNet per forward)."""
@@ -352,8 +381,7 @@ class Attention(nn.Module):
         `seq_ln` = the LayerNorm module in front (caller checked seq_ok): `normed` is the un-normalised tensor; LayerNorm, Q|K|V
         and the attention over the frames of each pixel run as one kernel, only the output projection follows."""
         if seq_ln is not None:
-            a = ops.seq_self_attention(normed, self.seq_packed(seq_ln), g.clips, g.hw, g.frames, (g.frames * g.hw, 1, g.hw),
-                                       scale=float(self.dim_head) ** -0.5)
+            a = self.seq_attention(normed, seq_ln, g)
             return self.to_out[0].tokens(a, residual=residual, **epilogue)
         if ln is None:
             qkv = ops.conv_gemm(normed, self.fused(), ops.linear_geom(normed.shape[0]))
@@ -425,13 +453,32 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim_out or dim)])
 
-    def tokens(self, x, residual, ln=None, tail=None):
-        """`tail` = (packed merged weights of _MergedTail, the transformer's outer residual): ff-out, `+ residual` and the
+    def tokens(self, x, residual, ln=None, tail=None, out=None):
+        """`tail` = (packed merged weights of _MergedTail, the transformer's outer residual[, ...]): ff-out, `+ residual` and the
         transformer's proj_out as one two-source contraction (FF_PROJ_MERGE)."""
         h = self.net[0].tokens(x, ln=ln)
         if tail is None:
             return self.net[2].tokens(h, residual=residual)
-        return ops.conv_gemm(h, tail[0], ops.linear_geom(h.shape[0]), x1=residual, residual=tail[1])
+        return ops.conv_gemm(h, tail[0], ops.linear_geom(h.shape[0]), x1=residual, residual=tail[1], out=out)
+
+    def fused_tokens(self, x, norm, tail):
+        """norm -> GEGLU -> ff-out -> + x -> proj_out -> + outer in ONE kernel (ops.ff_fused; tail = (merged weights, outer, ops.FFFused)); x is
+        the UN-normalised residual stream.  With FF_SPLIT the rows behind the last full round of tiles take the two contractions."""
+        rows = x.shape[0]
+        mt, outer, pk = tail
+        m = rows
+        if FF_SPLIT and x.is_cuda:
+            per_round = 128 * torch.cuda.get_device_properties(x.device).multi_processor_count
+            full = rows // per_round * per_round
+            if 0 < rows - full <= per_round // 2 and full > 0:
+                m = full
+        if m == rows:
+            return ops.ff_fused(x, pk, outer)
+        out = torch.empty_like(x)
+        ops.ff_fused(x[:m], pk, outer[:m], out=out[:m])
+        xr = x[m:]
+        self.tokens(norm.tokens(xr), residual=xr, tail=(mt, outer[m:]), out=out[m:])
+        return out
 
 
 class BasicTransformerBlock(nn.Module):
@@ -445,18 +492,41 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.double_self_attention = double_self_attention
 
-    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0, dup: int = 1, x_stats=None, tail=None):
+    def seq_pair_ok(self, x, g: Grid, temporal: bool):
+        """Both attention layers on ops.seq_self_attention with the linear layers in front inside (see `tokens`)."""
+        return SEQ_PRE and not self.attn2.is_cross and self.attn1.seq_ok(x, g, temporal) and self.attn2.seq_ok(x, g, temporal)
+
+    def tokens(self, x, g: Grid, temporal: bool, text=None, text_len=0, dup: int = 1, x_stats=None, tail=None, pre_in=None):
         """`dup` > 1: x holds ONE copy of `dup` identical groups of clips (classifier-free guidance runs the same latents
         with two prompts, models/pipeline.py:165): the self-attention - which never sees the text - is computed once and
         its result replicated in front of the cross-attention; `g` describes the single copy.
         `x_stats`: ops.RowStats of x left by the contraction that produced it.  With LN_FOLD the three LayerNorms never run as
         kernels: each is folded into the projection behind it (Q|K|V, Q, GEGLU) and its row statistics come out of the epilogue
         of the projection in front of it (proj_in, to_out + residual); a producer that cannot emit them (split K, compiled
-        tiles) leaves None and that LayerNorm runs as a kernel."""
+        tiles) leaves None and that LayerNorm runs as a kernel.
+        `pre_in`: the transformer's proj_in (a Linear), NOT yet applied to x - it runs inside the first attention kernel (seq_pair_ok)."""
         fold = LN_FOLD
-        fold_ff = fold and LN_FOLD_FF
+        ff_one = tail is not None and len(tail) > 2 and tail[2] is not None and ops.ff_fused_ok(x.shape[1], x.shape[0] * dup, x.dtype)
+        fold_ff = fold and LN_FOLD_FF and not ff_one          # (ops.ff_fused normalises its rows itself: no statistics from the producer)
         seq1 = self.attn1.seq_ok(x, g, temporal)
         seq2 = not self.attn2.is_cross and self.attn2.seq_ok(x, g, temporal)
+        if seq1 and seq2 and SEQ_PRE and dup == 1:
+            # both attention layers as two kernels: [pre_in (proj_in) ->] norm1 -> attn1, then attn1.to_out + residual -> norm2 -> attn2; only
+            # attn2's output projection remains a contraction (it leaves norm3's statistics)
+            if pre_in is not None:
+                a, x = self.attn1.seq_attention(x, self.norm1, g, pre=pre_in)
+            else:
+                a = self.attn1.seq_attention(x, self.norm1, g)
+            a, x = self.attn2.seq_attention(a, self.norm2, g, pre=self.attn1.to_out[0], residual=x)
+            r = self.attn2.to_out[0].tokens(a, residual=x, row_stats=fold_ff, coef_eps=self.norm3.eps)
+            x, st = r if fold_ff else (r, None)
+            if ff_one:
+                return self.ff.fused_tokens(x, self.norm3, tail)
+            if st is not None:
+                return self.ff.tokens(x, residual=x, ln=(self.norm3, st), tail=tail)
+            return self.ff.tokens(self.norm3.tokens(x), residual=x, tail=tail)
+        if pre_in is not None:
+            raise RuntimeError("BasicTransformerBlock: `pre_in` needs both attention layers on the fused path")
         if seq1:                                          # norm1 + Q|K|V + attention in one kernel; norm2's statistics only if its consumer folds it
             want = fold and not seq2
             r = self.attn1.self_tokens(x, x, g, temporal, seq_ln=self.norm1, row_stats=want, coef_eps=self.norm2.eps)
@@ -481,6 +551,8 @@ class BasicTransformerBlock(nn.Module):
             else:
                 r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, row_stats=fold_ff, coef_eps=self.norm3.eps)
         x, st = r if fold_ff else (r, None)
+        if ff_one:
+            return self.ff.fused_tokens(x, self.norm3, tail)
         if st is not None:
             return self.ff.tokens(x, residual=x, ln=(self.norm3, st), tail=tail)
         return self.ff.tokens(self.norm3.tokens(x), residual=x, tail=tail)
@@ -493,6 +565,7 @@ class _MergedTail:
 
     def _apply(self, fn, *a, **k):
         self._mt = None
+        self._ffk = None
         return super()._apply(fn, *a, **k)
 
     def merged_tail(self):
@@ -519,6 +592,24 @@ class _MergedTail:
             self._mt_key = key
         return self._mt or None
 
+    _ffk = None
+    _ffk_key = None
+
+    def fused_ff(self):
+        """The last block's norm3 / FeedForward and proj_out as the weight stream of ops.ff_fused (None where the library has no such kernel
+        for this width or the merged weights failed merged_tail()'s rounding check)."""
+        blk = self.transformer_blocks[-1]
+        w1 = blk.ff.net[0].proj
+        if not FF_FUSED or w1.in_features != 320 or self.merged_tail() is None:
+            return None
+        ff_out, n3 = blk.ff.net[2], blk.norm3
+        key = weights_key(w1.weight, w1.bias, ff_out.weight, ff_out.bias, self.proj_out.weight, self.proj_out.bias, n3.weight, n3.bias)
+        if self._ffk is None or self._ffk_key != key:
+            self._ffk = ops.pack_ff_fused(w1.weight, w1.bias, ff_out.weight, ff_out.bias, self.proj_out.weight, self.proj_out.bias,
+                                          ln=(n3.weight, n3.bias, n3.eps))
+            self._ffk_key = key
+        return self._ffk
+
 
 class Transformer2DModel(_MergedTail, nn.Module):
     """diffusers Transformer2DModel(use_linear_projection=True)."""
@@ -539,7 +630,7 @@ class Transformer2DModel(_MergedTail, nn.Module):
         mt, last = self.merged_tail(), len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             h = blk.tokens(h, g, temporal=False, text=text, text_len=text_len, dup=dup if i == 0 else 1, x_stats=st if i == 0 else None,
-                           tail=(mt, outer) if mt is not None and i == last else None)
+                           tail=(mt, outer, self.fused_ff()) if mt is not None and i == last else None)
             if i == 0 and dup > 1:
                 g = replace(g, clips=g.clips * dup)
         return h if mt is not None else self.proj_out.tokens(h, residual=outer)
@@ -563,9 +654,14 @@ class TransformerTemporalModel(_MergedTail, nn.Module):
         # (norm1's statistics are only wanted when the first attention layer folds it: ops.seq_self_attention normalises in its registers)
         want = LN_FOLD and not (SEQ_ATTN and blk0.attn1.inner in SEQ_ATTN_CHANNELS and blk0.attn1.dim_head == 64 and self.proj_in.out_features == blk0.attn1.inner
                                 and ops.seq_self_attention_ok(blk0.attn1.inner, g.frames, x.shape[0], x.dtype))
-        h, st = self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw), row_stats=True, coef_eps=blk0.norm1.eps) if want else \
-                (self.proj_in.tokens(self.norm.tokens(x, g.clips, g.frames * g.hw)), None)
+        xn = self.norm.tokens(x, g.clips, g.frames * g.hw)
         mt, last = self.merged_tail(), len(self.transformer_blocks) - 1
+        if blk0.seq_pair_ok(xn, g, True) and self.proj_in.out_features == self.proj_in.in_features == blk0.attn1.inner:
+            h = xn                                        # proj_in runs inside the first attention kernel
+            for i, blk in enumerate(self.transformer_blocks):
+                h = blk.tokens(h, g, temporal=True, tail=(mt, x, self.fused_ff()) if mt is not None and i == last else None, pre_in=self.proj_in if i == 0 else None)
+            return h if mt is not None else self.proj_out.tokens(h, residual=x)
+        h, st = self.proj_in.tokens(xn, row_stats=True, coef_eps=blk0.norm1.eps) if want else (self.proj_in.tokens(xn), None)
         for i, blk in enumerate(self.transformer_blocks):
-            h = blk.tokens(h, g, temporal=True, x_stats=st if i == 0 else None, tail=(mt, x) if mt is not None and i == last else None)
+            h = blk.tokens(h, g, temporal=True, x_stats=st if i == 0 else None, tail=(mt, x, self.fused_ff()) if mt is not None and i == last else None)
         return h if mt is not None else self.proj_out.tokens(h, residual=x)

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (AA_ACT_GELU, AA_ACT_NONE, AA_ACT_QUICK_GELU, AA_ACT_SILU, AA_BF16, AA_F16, AA_F32, AaAttention, AaAttnOperand,
-                   AaBlend, AaConvGemm, AaDpmStep, AaDpmStepTok, AaEulerStepTok, AaGroupNorm, AaPackFrames, AaPackLatents, AaSeqSelfAttn)
+                   AaBlend, AaConvGemm, AaFFFused, AaDpmStep, AaDpmStepTok, AaEulerStepTok, AaGroupNorm, AaPackFrames, AaPackLatents, AaSeqSelfAttn)
 
 _DT = {torch.float16: AA_F16, torch.bfloat16: AA_BF16, torch.float32: AA_F32}
 
@@ -33,11 +33,11 @@ GN_PLANS = None            # a list: groupnorm() appends (groups per workgroup, 
 MAX_OPERAND_BYTES = 1 << 31      # the contraction kernel's 32-bit operand offsets
 FORCE_TILE = -1       # tests / sweeps: >= 0 puts this tile-table index into AaConvGemm.tile of every conv_gemm call (strict: ineligible = error)
 # experiments: AaAttention._pad.  bit 0 (1): s_setprio 1 around the matrix clusters of the head_dim-64 kernel; bit 2 (4): short key sequences take the
-# general kernel instead of attention_shortkv_kernel (A/B).  (The eager row maximum of rounds 2-4 is a COMPILE-time variant: build.build(variant=
+# general kernel instead of attention_shortkv_kernel (A/B); bit 3 (8): long sequences take the two-query-blocks-per-wave kernel (round 6 experiment: slower, profiles/r06g_*).  (The eager row maximum of rounds 2-4 is a COMPILE-time variant: build.build(variant=
 # ("eager", ["-DAA_ATTN_EAGER_MAX=1"])) loaded through AA_LIBRARY - there is no run-time bit for it.)  Unknown bits are rejected.
 ATTN_FLAGS = int(os.environ.get("AA_ATTN_FLAGS", "0"))
-if ATTN_FLAGS & ~5:
-    raise RuntimeError(f"AA_ATTN_FLAGS={ATTN_FLAGS}: only bits 0 (value 1) and 2 (value 4) exist")
+if ATTN_FLAGS & ~13:
+    raise RuntimeError(f"AA_ATTN_FLAGS={ATTN_FLAGS}: only bits 0 (value 1), 2 (value 4) and 3 (value 8) exist")
 # A folded LayerNorm's row statistics reach the consumer as aa_ln_finalize's per-row coefficients (one 4.7 us launch per consumer, 99 per
 # step) or raw (ABI 106 `ln_parts`: the consumer finalises 2 / 10 partial sums per row itself with independent loads).  Measured (r04h/i):
 # the raw form removes 80 launches (-0.37 ms) and costs the K = 320 ... 1280 consumers 4-7 % (+0.7 ms: square root, reciprocal and the
@@ -764,6 +764,25 @@ def pack_seq_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, ln=None) 
     return SeqQKV(order(w3), bias, float(eps))
 
 
+@dataclass
+class SeqPre:
+    """A linear layer run INSIDE aa_seq_self_attention in front of the normalisation (AaSeqSelfAttn.pre_w): `w` [C / 64, 64, C] = its rows
+    in 64-row passes, each 32-row half in the order 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); `bias` fp32 [C] in the same order."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+
+
+def pack_seq_pre(weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> SeqPre:
+    """nn.Linear(C, C) (diffusers Transformer*Model.proj_in, Attention.to_out[0]) -> the `pre` operand of seq_self_attention."""
+    n, c = weight.shape
+    assert n == c and n % 64 == 0
+    i = torch.arange(32, device=weight.device)
+    perm = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)
+    rows = (torch.arange(0, n, 32, device=weight.device)[:, None] + perm[None, :]).reshape(-1)
+    b = None if bias is None else bias.detach().float()[rows].contiguous()
+    return SeqPre(weight.detach()[rows].reshape(n // 64, 64, c).contiguous(), b)
+
+
 def _seq_self_attn_desc(x, pk, out, n_outer, n_inner, seq_len, strides, scale):
     d = AaSeqSelfAttn()
     d.x, d.w, d.w_bias, d.o = _ptr(x), _ptr(pk.w), _ptr(pk.bias), _ptr(out)
@@ -786,17 +805,154 @@ def seq_self_attention_ok(channels: int, seq_len: int, rows: int, dtype) -> bool
     return bool(_lib.get().aa_seq_self_attention_ok(C.byref(d)))
 
 
-def seq_self_attention(x: torch.Tensor, pk: SeqQKV, n_outer: int, n_inner: int, seq_len: int, strides, scale: Optional[float] = None) -> torch.Tensor:
+def seq_self_attention(x: torch.Tensor, pk: SeqQKV, n_outer: int, n_inner: int, seq_len: int, strides, scale: Optional[float] = None,
+                       pre: Optional[SeqPre] = None, residual: Optional[torch.Tensor] = None):
     """softmax(q k^T * scale) v with [q | k | v] = LayerNorm(x) W^T for every (outer, inner) sequence and head (head_dim 64), in one
     kernel; `pk` from pack_seq_qkv (with the LayerNorm folded in, or without one), `strides` = (outer, inner, pos) row strides of x
-    (and of the result, [rows, C])."""
+    (and of the result, [rows, C]).
+    `pre` (pack_seq_pre): the same kernel first runs x' = x W_pre^T + b_pre (+ residual), writes it and attends over LayerNorm(x') -
+    the projection in front of the block (proj_in) or the previous attention layer's to_out + residual.  Returns (o, x') then."""
     lib = _lib.get()
-    _check(x, pk.w, pk.bias)
+    _check(x, pk.w, pk.bias, residual)
     if pk.w.dtype != x.dtype or pk.w.shape[-1] != x.shape[1]:
         raise RuntimeError("seq_self_attention: weights were packed for another dtype / width")
     out = torch.empty(x.shape[0], x.shape[1], dtype=x.dtype, device=x.device)
     d = _seq_self_attn_desc(x, pk, out, n_outer, n_inner, seq_len, strides, 64.0 ** -0.5 if scale is None else scale)
+    x_pre = None
+    if pre is not None:
+        _check(pre.w, pre.bias)
+        if pre.w.dtype != x.dtype or pre.w.shape[-1] != x.shape[1]:
+            raise RuntimeError("seq_self_attention: the projection in front was packed for another dtype / width")
+        x_pre = torch.empty_like(out)
+        d.pre_w, d.pre_bias, d.pre_residual, d.pre_out = _ptr(pre.w), _ptr(pre.bias), _ptr(residual), _ptr(x_pre)
+        d.ld_res, d.ld_pre = 0 if residual is None else residual.stride(0), x_pre.stride(0)
+    elif residual is not None:
+        raise RuntimeError("seq_self_attention: `residual` belongs to the projection in front (`pre`)")
     _run(lib.aa_seq_self_attention, C.byref(d), _stream(x))
+    return out if pre is None else (out, x_pre)
+
+
+# ------------------------------------------------------------------------------------- FeedForward + proj_out in one kernel
+FF_FUSED_DEBUG = 0     # profiling only: AaFFFused.flags (timing ablations)
+
+
+FF_STAGE_BYTES, FF_STAGES = 41984, 65          # include/aa_mi355.h: AA_FF_STAGE_BYTES, AA_FF_STAGES
+
+
+@dataclass
+class FFFused:
+    """Operand of aa_ff_fused (include/aa_mi355.h): `w` = the weight stream, [65, 41984 / 2] of the storage type - the LDS stage images of
+    GEGLU.proj (LayerNorm folded in), Wp W2 and Wp in the order the kernel consumes them, biases as (hi, lo) rows; see pack_ff_fused."""
+    w: torch.Tensor
+    ln_eps: float
+    normalize: bool
+
+
+def _bias_hi_lo(b: Optional[torch.Tensor], n: int, dtype, device) -> torch.Tensor:
+    """fp32 bias [n] (None: zeros) -> [n, 8] of the storage type: (hi, lo, 0 x 6) with hi = round(b), lo = round(b - hi) - the A operand of the
+    bias k-slice of aa_ff_fused (the matrix pipe adds hi * 1 + lo * 1 in fp32: the bias to 2^-22 (fp16) / 2^-16 (bf16) relative)."""
+    out = torch.zeros(n, 8, dtype=dtype, device=device)
+    if b is not None:
+        hi = b.to(dtype)
+        out[:, 0], out[:, 1] = hi, (b - hi.float()).to(dtype)
+    return out
+
+
+def _ff_stage_image(block: torch.Tensor, bias8: Optional[torch.Tensor], k_chunks: bool) -> torch.Tensor:
+    """One LDS stage image [41984 / 2]: `block` = [64, 320] (64 weight rows x all K: five K chunks of 64) or [320, 64] (all rows x 64 K: five
+    row chunks of 64); every chunk [64 rows][8 slots][8] with slot s of row r holding source slot s ^ ((r >> 1) & 7); then `bias8` [64, 8]
+    (zeros if None)."""
+    dev = block.device
+    chunks = block.reshape(64, 5, 64).permute(1, 0, 2) if k_chunks else block.reshape(5, 64, 64)       # [5][64 rows][64 K]
+    r = torch.arange(64, device=dev)[:, None]
+    src_slot = torch.arange(8, device=dev)[None, :] ^ ((r >> 1) & 7)                                    # [64, 8]
+    sw = torch.gather(chunks.reshape(5, 64, 8, 8), 2, src_slot[None, :, :, None].expand(5, 64, 8, 8))
+    b = torch.zeros(64, 8, dtype=block.dtype, device=dev) if bias8 is None else bias8
+    return torch.cat([sw.reshape(-1), b.reshape(-1)])
+
+
+def pack_ff_fused(w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, b2: Optional[torch.Tensor],
+                  wp: Optional[torch.Tensor] = None, bp: Optional[torch.Tensor] = None, ln=None) -> FFFused:
+    """diffusers FeedForward = GEGLU.proj (w1 [8 C, C]: value rows, then gate rows; b1) -> value * gelu(gate) -> Linear (w2 [C, 4 C], b2), `+ x`
+    behind it, and the transformer wrapper's proj_out (wp [C, C], bp; None: identity) -> the weight stream of ff_fused:
+        out = [h | x] [Wp W2 | Wp]^T + (Wp b2 + bp) + outer.
+    The product Wp W2 is formed in fp32 and rounded once (layers._MergedTail checks that this is harmless for the weights at hand).
+    `ln` = (gamma, beta, eps) folds the LayerNorm in front of GEGLU.proj as pack_weight(ln=...) does."""
+    c = w1.shape[1]
+    hid = w2.shape[1]
+    assert c == 320 and w1.shape == (2 * hid, c) and w2.shape == (c, hid) and hid == 4 * c
+    dt, dev = w1.dtype, w1.device
+    w1f = w1.detach().float()
+    b1f = None if b1 is None else b1.detach().float()
+    eps, normalize = 0.0, False
+    if ln is not None:
+        gamma, beta, eps = ln
+        extra = w1f @ beta.detach().float()
+        b1f = extra if b1f is None else b1f + extra
+        w1f = w1f * gamma.detach().float()[None, :]
+        normalize = True
+    # W1 chunk ch of 64 rows: value rows of hidden units 32 ch .. + 31, then their gate rows
+    idx = torch.arange(hid, device=dev).reshape(hid // 32, 32)
+    rows1 = torch.cat([idx, idx + hid], dim=1).reshape(-1)
+    w1p = w1f[rows1].to(dt)
+    b1p = _bias_hi_lo(None if b1f is None else b1f[rows1], 2 * hid, dt, dev)
+    wpf = torch.eye(c, device=dev) if wp is None else wp.detach().float()
+    wh = wpf @ w2.detach().float()                                                  # [C, 4 C]
+    bm = None
+    if b2 is not None or bp is not None:
+        bm = (0.0 if bp is None else bp.detach().float()) + (0.0 if b2 is None else wpf @ b2.detach().float())
+    i = torch.arange(32, device=dev)
+    perm = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)
+    rows = (torch.arange(0, c, 32, device=dev)[:, None] + perm[None, :]).reshape(-1)
+    # hidden axis: position 32 cc + 16 h + 8 t + e of every 64 holds unit 32 cc + (e & 3) + 4 h + 8 (e >> 2) + 16 t (the order in which a lane's
+    # accumulator registers of value * gelu(gate) become the B operand of the second product)
+    pz = torch.arange(64, device=dev)
+    cc, hh, tt, ee = pz >> 5, (pz >> 4) & 1, (pz >> 3) & 1, pz & 7
+    unit = 32 * cc + (ee & 3) + 4 * hh + 8 * (ee >> 2) + 16 * tt
+    cols = (torch.arange(0, hid, 64, device=dev)[:, None] + unit[None, :]).reshape(-1)
+    whp, wxp = wh[rows][:, cols].to(dt), wpf[rows].to(dt)
+    bmp = _bias_hi_lo(None if bm is None else bm[rows], c, dt, dev)
+    stage_x = lambda n: _ff_stage_image(wxp[64 * n:64 * n + 64], bmp[64 * n:64 * n + 64], True)
+    stage_w1 = lambda ch: _ff_stage_image(w1p[64 * ch:64 * ch + 64], b1p[64 * ch:64 * ch + 64], True)
+    stage_h = lambda g: _ff_stage_image(whp[:, 64 * g:64 * g + 64], None, False)
+    npair = hid // 64
+    seq = [stage_x(n) for n in range(c // 64)] + [stage_w1(0), stage_w1(1)]
+    for g in range(1, npair):
+        seq += [stage_w1(2 * g), stage_h(g - 1), stage_w1(2 * g + 1)]
+    seq.append(stage_h(npair - 1))
+    w = torch.stack(seq).contiguous()
+    assert w.shape == (FF_STAGES, FF_STAGE_BYTES // 2)
+    return FFFused(w, float(eps), normalize)
+
+
+def _ff_fused_desc(x, pk, outer, out):
+    d = AaFFFused()
+    d.x, d.outer, d.out, d.w = _ptr(x), _ptr(outer), _ptr(out), _ptr(pk.w)
+    d.rows, d.channels = x.shape[0], x.shape[1]
+    d.ldx, d.ld_outer, d.ldo = x.stride(0), 0 if outer is None else outer.stride(0), out.stride(0)
+    d.normalize, d.ln_eps, d.dtype, d.flags = int(pk.normalize), pk.ln_eps, _DT[x.dtype], FF_FUSED_DEBUG
+    return d
+
+
+def ff_fused_ok(channels: int, rows: int, dtype) -> bool:
+    d = AaFFFused()
+    d.rows, d.channels, d.ldx, d.ld_outer, d.ldo, d.dtype = rows, channels, channels, channels, channels, _DT.get(dtype, -1)
+    return bool(_lib.get().aa_ff_fused_ok(C.byref(d)))
+
+
+def ff_fused(x: torch.Tensor, pk: FFFused, outer: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[GEGLU(LayerNorm(x) W1^T + b1) | x] Wm^T + bm + outer in one kernel (pk from pack_ff_fused): the FeedForward of a transformer block, its
+    residual, the wrapper's proj_out and the wrapper's residual; the [rows, 4 C] activation is never written."""
+    lib = _lib.get()
+    _check(x, outer, pk.w, out)
+    if pk.w.dtype != x.dtype or x.shape[1] != 320:
+        raise RuntimeError("ff_fused: weights were packed for another dtype / width")
+    if out is None:
+        out = torch.empty(x.shape[0], x.shape[1], dtype=x.dtype, device=x.device)
+    elif out.shape != x.shape or out.dtype != x.dtype or out.stride(1) != 1:
+        raise RuntimeError("ff_fused: `out` must have x's shape and dtype")
+    d = _ff_fused_desc(x, pk, outer, out)
+    _run(lib.aa_ff_fused, C.byref(d), _stream(x))
     return out
 
 

@@ -275,12 +275,22 @@ typedef struct AaSeqSelfAttn {
     const void* x;          /* [rows][ldx] storage dtype */
     const void* w;          /* [channels / 64][3][64][channels] storage dtype */
     const float* w_bias;    /* [channels / 64][3][64] fp32: what the projections start from (W beta of a folded LayerNorm), or NULL */
+    /* A linear layer IN FRONT, inside the same kernel (NULL pre_w: none): x' = x W_pre^T + pre_bias (+ pre_residual) is computed per tile,
+     * rounded to the storage type, written to pre_out, and the attention runs over (the normalised) x' - diffusers
+     * TransformerTemporalModel.proj_in in front of the first attention layer, or the first layer's to_out[0] + residual in front of the
+     * second (reference unet_3d_blocks.py:379 via BasicTransformerBlock).  pre_w: [channels / 64][64][channels] storage dtype, the rows of
+     * each 32-row half in the order 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); pre_bias: fp32 [channels] in the same order. */
+    const void* pre_w;
+    const float* pre_bias;      /* may be NULL */
+    const void* pre_residual;   /* [rows][ld_res] storage dtype, rows addressed like x; may be NULL */
+    void* pre_out;              /* [rows][ld_pre] storage dtype; required with pre_w */
     void* o;                /* [rows][ldo] storage dtype */
     int64_t outer_stride, inner_stride, pos_stride;   /* in rows */
     int64_t x_bytes, o_bytes;   /* extents of x and o the call may touch (each < 2 GiB: 32-bit offsets through buffer descriptors) */
     int32_t n_outer, n_inner, seq_len;
     int32_t channels;
     int32_t ldx, ldo;       /* row pitches in elements, multiples of 8 */
+    int32_t ld_res, ld_pre; /* row pitches of pre_residual / pre_out (multiples of 8; extents like x's: < 2 GiB) */
     int32_t normalize;      /* 1: rows of x are normalised to zero mean / unit variance (ln_eps) in front of the projections; 0: x as it is */
     float ln_eps;
     float scale;            /* head_dim ** -0.5 */
@@ -293,6 +303,42 @@ typedef struct AaSeqSelfAttn {
  * concatenated Q|K|V rows, aa_attention) - looks at channels, seq_len, strides and extents only. */
 int aa_seq_self_attention_ok(const AaSeqSelfAttn* d);
 int aa_seq_self_attention(const AaSeqSelfAttn* d, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * aa_ff_fused (version 108): the FeedForward of a transformer block and the transformer wrapper's proj_out behind it as ONE kernel -
+ *     out = [ GEGLU(LayerNorm(x) W1^T + b1) | x ] Wm^T + bm + outer,        Wm = [Wp W2 | Wp],  bm = Wp b2 + bp
+ * diffusers BasicTransformerBlock.norm3 -> FeedForward(GEGLU, Linear) -> + x, then Transformer2DModel / TransformerTemporalModel.proj_out
+ * -> + the transformer's input `outer` (reference models/unet_3d_blocks.py:287,446,681 and :379,526,759).  The GEGLU activation
+ * [rows][4 * channels] is never written.  channels == 320 (aa_ff_fused_ok); elsewhere the caller runs the two aa_conv_gemm calls.
+ * `w` is the weight STREAM the kernel copies into its LDS ring stage by stage (ops.pack_ff_fused builds it; csrc/kernels/ff_fused.h consumes
+ * it): 65 stage images of 41 KB (AA_FF_STAGE_BYTES) in the order  X0..X4, A(0), B(0), { A(g), H(g - 1), B(g) } g = 1..19, H(19):
+ *   X(i)   rows 64 i .. + 63 of Wm_x = Wp (every 32-row block in the order 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)), all 320 K;
+ *   A / B(g) the 64 rows of W1 chunk 2 g / 2 g + 1: the value rows of hidden units 32 ch .. + 31, then their gate rows (GEGLU.proj with
+ *          LayerNorm's gamma folded in), all 320 K;
+ *   H(g)   Wm_h = Wp W2: all 320 rows (in the row order of X), the 64 hidden units 64 g .. + 63 as K in the order
+ *          position 32 cc + 16 h + 8 t + e  <-  unit 32 cc + (e & 3) + 4 h + 8 (e >> 2) + 16 t;
+ * an image = five [64][64] chunks (K chunks of the 64 rows for X / A / B, 64-row chunks of the 64 K for H), every row 128 bytes whose 16-byte
+ * slots s hold source slot s ^ ((row >> 1) & 7), followed by 1 KB of bias rows [64][8] = (hi, lo, 0, 0, 0, 0, 0, 0) per weight row with
+ * hi + lo = the row's fp32 bias (bm = Wp b2 + bp for X; GEGLU bias + W1 beta for A / B; zeros for H) - the kernel adds them on the matrix pipe.
+ * ---------------------------------------------------------------------------------------------- */
+#define AA_FF_STAGE_BYTES 41984
+#define AA_FF_STAGES 65
+typedef struct AaFFFused {
+    const void* x;          /* [rows][ldx] storage dtype: the block's residual stream (un-normalised) */
+    const void* outer;      /* [rows][ld_outer] storage dtype: the transformer's input (the wrapper's residual); may be NULL */
+    void* out;              /* [rows][ldo] */
+    const void* w;          /* AA_FF_STAGES x AA_FF_STAGE_BYTES: the weight stream (see above), storage dtype */
+    int64_t rows;
+    int32_t channels;
+    int32_t ldx, ld_outer, ldo;    /* row pitches in elements, multiples of 8; every operand < 2 GiB */
+    int32_t normalize;      /* 1: rows of x are normalised (ln_eps) in front of W1 (gamma / beta folded into the stream) */
+    float ln_eps;
+    int32_t dtype;          /* AA_F16 | AA_BF16 */
+    int32_t flags;          /* 0 (timing ablations of scripts/bench_ff_fused.py: see csrc/kernels/ff_fused.h) */
+} AaFFFused;
+
+int aa_ff_fused_ok(const AaFFFused* d);
+int aa_ff_fused(const AaFFFused* d, void* stream);
 
 /* aa_softmax_rows: y[r, :] = softmax(x[r, :]) for fp32 scores (VAE mid-block single-head
  * attention, head_dim 512, where scores are materialised: diffusers Attention with

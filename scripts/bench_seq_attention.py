@@ -51,9 +51,13 @@ def case(C, clips, frames, hw):
     pwo = ops.pack_weight(wo, bo)
     out_call = lambda: ops.conv_gemm(a, pwo, ops.linear_geom(rows), residual=x)
     t_f, t_q, t_a, t_o = timed(fused), timed(qkv_call), timed(attn_call), timed(out_call)
+    # with the linear layer in front inside the kernel (the previous attention layer's to_out + residual, or proj_in)
+    pre = ops.pack_seq_pre(wo, bo)
+    t_p = timed(lambda: ops.seq_self_attention(a, w_seq, clips, hw, frames, st, pre=pre, residual=x))
     flops = 2.0 * rows * C * 3 * C + 4.0 * rows * frames * C
     print(f"C={C} rows={rows} (clips {clips}, frames {frames}, hw {hw}): fused {t_f:.1f} us ({flops / t_f * 1e-6:.0f} TF/s, {2 * rows * C * 2 / t_f * 1e-3:.0f} GB/s x+o)"
-          f" | Q|K|V {t_q:.1f} + attention {t_a:.1f} = {t_q + t_a:.1f} us | to_out {t_o:.1f} us | max |fused - three-launch| {err:.4f}")
+          f" | Q|K|V {t_q:.1f} + attention {t_a:.1f} = {t_q + t_a:.1f} us | to_out {t_o:.1f} us | to_out + residual inside the fused kernel {t_p:.1f} us"
+          f" (apart {t_o + t_f:.1f}) | max |fused - three-launch| {err:.4f}")
 
 
 def ablations(C, clips, frames, hw):

@@ -234,3 +234,59 @@ def test_ff_out_and_proj_out_as_one_contraction(emu, monkeypatch, temporal):
         ref.load_state_dict({k: v.float() for k, v in net.state_dict().items()})
     again, _ = run()
     assert rel_err(again, want()) < 2e-2 and rel_err(again, merged) > 0.05
+
+
+@pytest.mark.parametrize("temporal", [False, True])
+def test_feedforward_and_proj_out_as_one_kernel(emu, monkeypatch, temporal):
+    """layers.FF_FUSED: norm3 -> GEGLU -> ff-out -> + x -> proj_out -> + residual of Transformer2DModel / TransformerTemporalModel at 320
+    channels as ONE kernel (ops.ff_fused; oracle/layers.py:205-284): against the oracle module, against the two-contraction form, two
+    contraction launches fewer per transformer (and no statistics epilogue on the producer), rebuilt when a weight changes in place."""
+    from animate_anything_amd import layers as L, ops
+    torch.manual_seed(3)
+    C, heads, g = 320, 5, L.Grid(1, 3, 3, 5)
+    if temporal:
+        ref, net = oracle.TransformerTemporalModel(heads, 64, C), L.TransformerTemporalModel(heads, 64, C)
+    else:
+        ref, net = oracle.Transformer2DModel(heads, 64, C, cross_attention_dim=64), L.Transformer2DModel(heads, 64, C, cross_attention_dim=64)
+    ref = ref.eval()
+    state = seeded_state(ref)
+    ref.load_state_dict(state)
+    net.load_state_dict(state)
+    net = net.half().eval()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(g.tokens, C, generator=gen)
+    text = torch.randn(g.clips * 7, 64, generator=gen)
+
+    def run():
+        ops.TRACE = []
+        with torch.no_grad():
+            y = net.tokens(x.half(), g) if temporal else net.tokens(x.half(), g, text.half(), 7)
+        n, ops.TRACE = len(ops.TRACE), None
+        return y.float(), n
+
+    def want():
+        x5 = x.reshape(g.clips, g.frames, g.h, g.w, C)
+        with torch.no_grad():
+            if temporal:
+                y = ref(x5.permute(0, 1, 4, 2, 3).reshape(g.images, C, g.h, g.w), num_frames=g.frames).sample
+            else:
+                y = ref(x5.permute(0, 1, 4, 2, 3).reshape(g.images, C, g.h, g.w),
+                        encoder_hidden_states=text.reshape(g.clips, 7, 64).repeat_interleave(g.frames, 0)).sample
+        return y.permute(0, 2, 3, 1).reshape(g.tokens, C)
+
+    assert L.FF_FUSED and net.fused_ff() is not None
+    fused, n_fused = run()
+    monkeypatch.setattr(L, "FF_FUSED", False)
+    two, n_two = run()
+    monkeypatch.setattr(L, "FF_FUSED", True)
+    w = want()
+    assert n_two - n_fused == 2                                # the GEGLU and the merged ff-out / proj_out contractions are gone
+    assert rel_err(fused, w) < 2e-2 and rel_err(two, w) < 2e-2
+    assert rel_err(fused, two) < 1e-2
+    with torch.no_grad():                                      # an in-place edit of any of its weights rebuilds the stream
+        net.proj_out.weight.mul_(0.5)
+        net.transformer_blocks[0].ff.net[0].proj.bias.add_(0.25)
+        net.transformer_blocks[0].norm3.weight.mul_(1.5)
+        ref.load_state_dict({k: v.float() for k, v in net.state_dict().items()})
+    again, _ = run()
+    assert rel_err(again, want()) < 2e-2 and rel_err(again, fused) > 0.05

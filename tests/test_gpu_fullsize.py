@@ -508,6 +508,41 @@ def test_three_steps_against_the_oracle_at_the_metric_configuration():
             f.write("\n".join(lines) + "\n")
 
 
+def test_eight_steps_against_the_oracle_at_the_metric_configuration():
+    """error growth over EIGHT of configs[1]'s 25 DPM-Solver++ steps (guidance 9, full architecture, 16 x 64 x 64) against the
+    oracle pipeline loop (tests/golden/pipeline_fullsize_16x64x64_8steps.pt), strict guidance form (what bench.py times), every step.
+    What is asserted: finite latents, the north star's latent MSE < 1e-3 at every one of the eight steps, normalised MSE < 1e-3, and the single
+    worst element inside one forward's bound per step taken (k x 3e-2 of the latent range - the bound of the three-step test; on random weights
+    at guidance 9 the dynamics amplify each step's rounding noise, the range itself grows 5.2 -> 14 over these steps).  What is NOT asserted or
+    claimed: anything about steps 9-25 - the per-step numbers are written to AA_PARITY_REPORT_8 so that DESIGN.md can quote the measured growth
+    instead of an extrapolation."""
+    fixture = os.path.join(HERE, "golden", "pipeline_fullsize_16x64x64_8steps.pt")
+    if not os.path.exists(fixture):
+        pytest.skip("golden not generated (tests/golden/make_fullsize_multistep_golden.py --steps 8)")
+    gold = torch.load(fixture)
+    want, ts = gold["latents"].float(), [int(t) for t in gold["timesteps"]]
+    assert gold["guidance_scale"] == 9.0 and want.shape[1:] == (1, 4, 16, 64, 64) and len(ts) == 8
+    i = fullsize_inputs(16, 64)
+    net = _fullsize_product(DT)
+    got = _denoise_steps(net, i, ts, False)
+    lines = []
+    for k in range(len(ts)):
+        w = want[k]
+        rng_ = w.abs().max().item()
+        mse = ((got[k] - w) ** 2).mean().item()
+        nmse = mse / (w ** 2).mean().item()
+        e = (got[k] - w).abs().max().item() / rng_
+        lines.append(f"step {k + 1} (t={ts[k]}, |x|max {rng_:.3f}): latent MSE {mse:.3g}, MSE / mean(x^2) {nmse:.3g}, max |error| / range {e:.3g}")
+        print(lines[-1])
+        assert torch.isfinite(got[k]).all()
+        assert mse < 1e-3 and nmse < 1e-3, lines[-1]
+        assert e < 3e-2 * (k + 1), lines[-1]
+    out = os.environ.get("AA_PARITY_REPORT_8")
+    if out:
+        with open(out, "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
 def test_three_steps_against_the_oracle_at_the_metric_configuration_bf16():
     """The same three oracle steps through the bf16 library path (`bench.py --dtype bf16`), both guidance forms, at the bf16 tolerance of
     this file (8 significant bits of storage against 11: MSE < 1e-2, max-normalised error < k x 1.5e-1 after k steps)."""

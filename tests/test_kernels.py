@@ -279,8 +279,8 @@ def test_attention_deferred_max(backend, Lq, Lkv, qs):
     close(o, ref, tol=1e-2)
 
 
-@pytest.mark.parametrize("Lq,Lkv", [(70, 520), (130, 330)])
-def test_attention_lazy_maximum(backend, Lq, Lkv):
+@pytest.mark.parametrize("Lq,Lkv,qo", [(70, 520, 0), (130, 330, 0), (600, 712, 0), (600, 712, 32), (530, 520, 160 + 32)])
+def test_attention_lazy_maximum(backend, Lq, Lkv, qo):
     """Round 5: after the first key tile the row maximum is looked at only when a lane's sum of exponentials says some p left the
     deferral range (p > 2^6, or overflowed).  Cases built to walk every branch of that test, against fp32 SDPA:
       * a staircase: each later 64-key tile holds a key that beats everything before it by ~3-4 bits (below the 6-bit threshold
@@ -289,7 +289,9 @@ def test_attention_lazy_maximum(backend, Lq, Lkv):
         the tile be exponentiated again from its untouched scores);
       * a flat row (every score equal: p = 1 for every key, the sums stay far below the threshold - no rescale after tile 0);
       * a row whose every later key is ~2 bits above the first tile's maximum (sums of 32 x 4 = 128 > 64 with no single p > 64:
-        the slow path fires, moves the maximum by more than a bit, and must not fire again on the next tile)."""
+        the slow path fires, moves the maximum by more than a bit, and must not fire again on the next tile).
+    Lq >= 512 and Lkv >= 512 run twice: the default kernel and the experimental one with two 32-query blocks per wave (round 6, ops.ATTN_FLAGS
+    bit 3) - `qo` puts the special rows into a wave's first or second block (the second block has its own slow path)."""
     n = 1
     q = rnd(n * Lq, 64, scale=1.0, seed=151)
     kv = rnd(n * Lkv, 128, scale=1.0, seed=152)
@@ -298,16 +300,21 @@ def test_attention_lazy_maximum(backend, Lq, Lkv):
     s = 8.0 / math.log2(math.e)                                         # (scores are q.k / 8: a key c * q / |q|^2 * s scores c bits)
     unit = lambda r: qq[0, r] / (qq[0, r] ** 2).sum()
     for t in range(1, Lkv // 64):                                       # staircase for query 3: + ~3.5 bits per tile
-        kk[0, 64 * t + 9, 0] = (unit(3) * s * (6.0 + 3.5 * t)).to(DT)
-    kk[0, Lkv - 40, 0] = (unit(11) * s * 300.0).to(DT)                  # overflowing spike for query 11
-    q[17] = 0                                                           # flat row: every score 0
-    kk[0, 64:, 0] += (unit(25) * s * 2.0).to(DT)                        # every later key ~2 bits up for query 25
-    o = ops.attention(q, 0, kv, 0, kv, 64, 1, n, 1, Lq, Lkv, (Lq, 0, 1), (Lkv, 0, 1))
+        kk[0, 64 * t + 9, 0] = (unit(qo + 3) * s * (6.0 + 3.5 * t)).to(DT)
+    kk[0, Lkv - 40, 0] = (unit(qo + 11) * s * 300.0).to(DT)             # overflowing spike for query 11
+    q[qo + 17] = 0                                                      # flat row: every score 0
+    kk[0, 64:, 0] += (unit(qo + 25) * s * 2.0).to(DT)                   # every later key ~2 bits up for query 25
     ref = sdpa(q.reshape(n, 1, Lq, 64), kk[:, :, 0].reshape(n, 1, Lkv, 64), kk[:, :, 1].reshape(n, 1, Lkv, 64)).reshape(n * Lq, 64)
-    assert torch.isfinite(o.float()).all()
-    close(o, ref, tol=1e-2)
-    for r in (3, 11, 17, 25):
-        close(o[r], ref[r], tol=1e-2)
+    for flags in ((0, 8) if Lq >= 512 and Lkv >= 512 else (0,)):
+        keep, ops.ATTN_FLAGS = ops.ATTN_FLAGS, flags
+        try:
+            o = ops.attention(q, 0, kv, 0, kv, 64, 1, n, 1, Lq, Lkv, (Lq, 0, 1), (Lkv, 0, 1))
+        finally:
+            ops.ATTN_FLAGS = keep
+        assert torch.isfinite(o.float()).all()
+        close(o, ref, tol=1e-2)
+        for r in (3, 11, 17, 25):
+            close(o[qo + r], ref[qo + r], tol=1e-2)
 
 
 def test_attention_cross_text(backend):

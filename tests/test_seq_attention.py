@@ -90,3 +90,27 @@ def test_seq_self_attention_strided_output_matches_three_launch_form(backend):
     three = ops.attention(qkv, 0, qkv, C, qkv, 2 * C, C // 64, clips, hw, frames, frames, st, st)
     err = (fused.float() - three.float()).abs().max().item()
     assert err <= 6e-3 * max(1.0, three.float().abs().max().item()), err
+
+
+@pytest.mark.parametrize("C,clips,frames,hw,with_res", [(320, 1, 17, 20, True), (320, 2, 17, 9, False), (512, 1, 17, 10, True), (640, 1, 9, 11, True)])
+def test_seq_self_attention_with_the_projection_in_front(backend, C, clips, frames, hw, with_res):
+    """`pre`: x' = x W_pre^T + b_pre (+ residual) inside the kernel (proj_in in front of the first attention layer of a temporal transformer,
+    the first layer's to_out + residual in front of the second): x' itself and the attention over LayerNorm(x') against fp32 torch."""
+    dev, dtype = backend, torch.float16
+    g = torch.Generator().manual_seed(21)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    rows = clips * frames * hw
+    x, res = r(rows, C).to(dtype), (r(rows, C).to(dtype) if with_res else None)
+    wp, bp = r(C, C, sc=C ** -0.5).to(dtype), r(C, sc=0.3).to(dtype)
+    wq, wk, wv = (r(C, C, sc=C ** -0.5).to(dtype) for _ in range(3))
+    gamma, beta = (1.0 + 0.3 * r(C)).to(dtype), (0.2 * r(C)).to(dtype)
+    xp = F.linear(x.float(), wp.float(), bp.float()) + (0.0 if res is None else res.float())
+    want_x = xp.to(dtype)
+    want_o = reference(want_x, wq, wk, wv, gamma, beta, 1e-5, clips, frames, hw)
+    to = lambda t: None if t is None else t.to(dev)
+    pk = ops.pack_seq_qkv(to(wq), to(wk), to(wv), ln=(to(gamma), to(beta), 1e-5))
+    o, x_pre = ops.seq_self_attention(to(x), pk, clips, hw, frames, (frames * hw, 1, hw), pre=ops.pack_seq_pre(to(wp), to(bp)), residual=to(res))
+    ex = (x_pre.float().cpu() - xp).abs().max().item()
+    assert ex <= 4e-3 * max(1.0, xp.abs().max().item()), ex                  # (one rounding to fp16)
+    eo = (o.float().cpu() - want_o).abs().max().item()
+    assert torch.isfinite(o.float()).all() and eo <= 1.5e-2 * max(1.0, want_o.abs().max().item()), eo
