@@ -834,7 +834,7 @@ int aa_ff_fused(const AaFFFused* d, void* stream) {
     const int abl = d->flags >> 8;             // timing ablations (scripts/bench_ff_fused.py --ablate): fp16 instantiations only
 #define AA_FF(ABL_) case ABL_: AA_LAUNCH((ff_fused_kernel<f16_t, 320, ABL_>), grid, block, ff_lds_bytes(), stream, *d); break
     if (abl && d->dtype == AA_F16) {
-        switch (abl) { AA_FF(1); AA_FF(4); AA_FF(8); AA_FF(16); AA_FF(32); AA_FF(33); AA_FF(24); AA_FF(61); AA_FF(256); AA_FF(64); AA_FF(128);
+        switch (abl) { AA_FF(1); AA_FF(4); AA_FF(8); AA_FF(16); AA_FF(32); AA_FF(33); AA_FF(24); AA_FF(61); AA_FF(256); AA_FF(64); AA_FF(128); AA_FF(512);
                        default: return fail(AA_E_SHAPE, "ff_fused: no instantiation for ablation %d", abl); }
     } else if (d->dtype == AA_F16) AA_LAUNCH((ff_fused_kernel<f16_t, 320>), grid, block, ff_lds_bytes(), stream, *d);
     else                    AA_LAUNCH((ff_fused_kernel<bf16_t, 320>), grid, block, ff_lds_bytes(), stream, *d);

@@ -71,6 +71,13 @@ __device__ __forceinline__ void async_copy16_buf(const BufRsrc& r, unsigned byte
 __device__ __forceinline__ u32x4 buf_load16(const BufRsrc& r, unsigned byte_offset) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.v, byte_offset, 0, 0));
 }
+// the same with the non-temporal hint (aux bit 1: nt): streamed once, not worth an L2 line that a re-read operand (weights) could keep
+__device__ __forceinline__ u32x4 buf_load16_nt(const BufRsrc& r, unsigned byte_offset) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.v, byte_offset, 0, 2));
+}
+__device__ __forceinline__ void buf_store16_nt(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r.v, byte_offset, 0, 2);
+}
 __device__ __forceinline__ void buf_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r.v, byte_offset, 0, 0);
 }

@@ -37,7 +37,7 @@ __host__ __device__ constexpr int ff_lds_bytes() { return FF_RING * FF_STAGE_BYT
 // ABL: timing ablations compiled as separate instantiations (AaFFFused.flags >> 8; results are garbage): 1 no GELU arithmetic, 4 no LDS-DMA pieces behind
 // the first two stages, 8 no fragment reads, 16 no MFMAs, 32 no bias k-slice;
 // experiments (results valid): 256: the fine side-work placement (GELU in thirds of a pair behind every MFMA); 64: coarse, two pairs at a time;
-// 128: no rotation of the DMA piece order between workgroups
+// 128: no rotation of the DMA piece order between workgroups; 512: x / outer / out accessed with the non-temporal hint
 template <typename T, int C, int ABL = 0>
 __global__ void __launch_bounds__(64 * FF_NW, 1) ff_fused_kernel(const AaFFFused p) {
     static_assert(C == 320, "one stage = five 64 x 64 chunks: 320 channels");
@@ -78,7 +78,10 @@ __global__ void __launch_bounds__(64 * FF_NW, 1) ff_fused_kernel(const AaFFFused
     {
         const unsigned xb = row_ok ? (unsigned)(row * p.ldx * 2) + (unsigned)(16 * h * 2) : OOB;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) xf[ks] = buf_load16(r_x, xb + (unsigned)((32 * (ks >> 1) + 8 * (ks & 1)) * 2));
+        for (int ks = 0; ks < NKS; ++ks) {
+            const unsigned o = xb + (unsigned)((32 * (ks >> 1) + 8 * (ks & 1)) * 2);
+            xf[ks] = (ABL & 512) ? buf_load16_nt(r_x, o) : buf_load16(r_x, o);
+        }
     }
     // the bias k-slice's B operand: k = 0, 1 (lanes h = 0) multiply the rows' (hi, lo)
     const u32x4 xone = u32x4{h == 0 ? ones_pair(T()) : 0u, 0u, 0u, 0u};
@@ -144,9 +147,8 @@ __global__ void __launch_bounds__(64 * FF_NW, 1) ff_fused_kernel(const AaFFFused
         const f32x2 val = f32x2{a[0][8 * t + e], a[0][8 * t + e + 1]};
         const f32x2 gat = f32x2{a[1][8 * t + e], a[1][8 * t + e + 1]};
         const f32x2 y = (ABL & 1) ? val : val * gelu_erf_2(gat);
-        union { T e2[2]; unsigned u; } pk;
-        pk.e2[0] = (T)y[0]; pk.e2[1] = (T)y[1];
-        hp[t][i & 3] = pk.u;
+        typedef T t2 __attribute__((ext_vector_type(2)));
+        hp[t][i & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(y, t2));          // (one v_cvt_pk_*_f32, round to nearest even)
     };
     // Side work of an A / B pass, by SLOT: slot 2 u + j sits behind MFMA j of k-slice u (42 slots).  An MFMA occupies the matrix pipe for 32 clk
     // and the wave issues in order: vector work queued behind a SECOND MFMA waits for the first one to leave the pipe, and a long run of vector
@@ -359,10 +361,11 @@ __global__ void __launch_bounds__(64 * FF_NW, 1) ff_fused_kernel(const AaFFFused
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             Pack8<T> r, v;
-            r.raw = buf_load16(r_res, rb + (unsigned)((32 * nb + 8 * t) * 2));          // (no outer residual: zeros)
+            r.raw = (ABL & 512) ? buf_load16_nt(r_res, rb + (unsigned)((32 * nb + 8 * t) * 2)) : buf_load16(r_res, rb + (unsigned)((32 * nb + 8 * t) * 2));          // (no outer residual: zeros)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.e[e] = (T)(oacc[nb][8 * t + e] + (float)r.e[e]);
-            buf_store16(r_o, ob + (unsigned)((32 * nb + 8 * t) * 2), v.raw);
+            if constexpr (ABL & 512) buf_store16_nt(r_o, ob + (unsigned)((32 * nb + 8 * t) * 2), v.raw);
+            else buf_store16(r_o, ob + (unsigned)((32 * nb + 8 * t) * 2), v.raw);
         }
 }
 

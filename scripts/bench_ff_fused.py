@@ -73,7 +73,7 @@ def ablations(rows, C=320):
                 (A(32), "no bias k-slice"), (A(33), "no GELU, no bias k-slice"), (A(8), "no fragment reads"), (A(16), "no MFMAs"),
                 (A(24), "no fragment reads, no MFMAs"), (A(61), "barriers, loops and the x / out traffic only"),
                 (A(256), "variant: fine side work (a third of a GELU pair behind every MFMA)"), (A(64), "variant: GELU two pairs per slot"),
-                (A(128), "variant: no rotation of the DMA piece order")]
+                (A(128), "variant: no rotation of the DMA piece order"), (A(512), "variant: x / outer / out non-temporal")]
     # three passes over all variants (the chip's clock under load drifts over the first seconds: a single pass favours whatever runs last)
     for _ in range(30):
         ops.ff_fused(x, pk, outer)

@@ -252,6 +252,9 @@ inline u32x4 buf_load16(const BufRsrc& r, unsigned byte_offset) {
     if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(&v, r.base + byte_offset, 16);
     return v;
 }
+inline u32x4 buf_load16_nt(const BufRsrc& r, unsigned byte_offset) { return buf_load16(r, byte_offset); }
+inline void buf_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v);
+inline void buf_store16_nt(const BufRsrc& r, unsigned byte_offset, u32x4 v) { buf_store16(r, byte_offset, v); }
 inline void buf_store16(const BufRsrc& r, unsigned byte_offset, u32x4 v) {
     if ((unsigned long long)byte_offset + 16 <= r.bytes) std::memcpy(const_cast<char*>(r.base) + byte_offset, &v, 16);
 }
