@@ -179,6 +179,11 @@ def audit_x_kernels(lib_path):
         upper_half_ok = "seq_self_attention_kernel" in k and _agpr > 0
         if any(t in k for t in ("attention_kernel", "attention_shortkv_kernel", "groupnorm_")) and (scratch or (spills and not upper_half_ok)):
             problems.append(f"{k}: scratch {scratch} bytes, {spills} VGPR spills in a hot kernel")
+    # the one-wave-per-SIMD FeedForward kernel lives at the edge of the register file too: no scratch, no spills (its ablation instantiations
+    # are profiling code and exempt)
+    for k, (_agpr, scratch, _vgpr, spills) in sorted(meta.items()):
+        if "ff_fused_kernel" in k and "ELi0EEE" in k and (scratch or spills):
+            problems.append(f"{k}: scratch {scratch} bytes, {spills} VGPR spills in a hot kernel")
     xk = {k: v for k, v in meta.items() if "conv_gemm_x_kernel" in k}
     if len(xk) < 16:                                        # 8 tiles x {fp16, bf16} at the very least
         problems.append(f"only {len(xk)} hand-scheduled kernels found")
@@ -190,6 +195,17 @@ def audit_x_kernels(lib_path):
             bodies[cur] = []
         elif cur is not None:
             bodies[cur].append(line)
+    # Hand-issued LDS reads (dev.h lds_read16_async*, lds_read_tr16_b64_async: `asm volatile` with an "=v" output): hipcc believes the
+    # destination is valid right behind the statement, the data arrives at the matching counted s_waitcnt.  Nothing may name such a register
+    # in between (a live-range split or a v_mov there would copy stale data - ADVICE r05).  Linear walk per kernel: LDS operations retire in
+    # order, `s_waitcnt lgkmcnt(N)` leaves at most N of them pending (scalar loads also count in the hardware counter: ignoring them is the
+    # conservative reading).
+    for name in sorted(bodies):
+        if not any(t in name for t in ("attention_kernel", "attention_shortkv_kernel", "ff_fused_kernel")):
+            continue
+        hit = pending_lds_read_violation(bodies[name])
+        if hit:
+            problems.append(f"{name}: {hit}")
     for name, (agpr, scratch, vgpr, spills) in sorted(xk.items()):
         bad = lambda what: problems.append(f"{name}: {what}")
         if scratch or spills:
@@ -228,6 +244,50 @@ def audit_x_kernels(lib_path):
                 bad("accumulation register outside the source's statements: " + line.strip())
                 break
     return problems
+
+
+def _vregs(tok):
+    """'v[4:7]' -> {4,5,6,7}; 'v12' -> {12}; anything else -> empty."""
+    import re
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def pending_lds_read_violation(lines):
+    """First instruction of a disassembled kernel body that names the destination of an LDS read which no s_waitcnt has retired yet
+    (None if there is none).  See audit_x_kernels."""
+    import re
+    pending = []                                            # destination register sets of LDS operations in issue order (empty set: a store)
+    for raw in lines:
+        line = raw.strip()
+        if not line or line.startswith(("//", ";")):
+            continue
+        ins = line.split("//")[0].strip()
+        op = ins.split()[0] if ins.split() else ""
+        toks = [t.strip() for t in re.split(r"[\s,]+", ins)[1:] if t.strip()]
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", ins)
+            if m:
+                keep = int(m.group(1))
+                pending = pending[len(pending) - keep:] if keep else []
+            continue
+        named = set()
+        for t in toks:
+            named |= _vregs(t)
+        busy = set().union(*pending) if pending else set()
+        if op.startswith("ds_"):
+            dst = _vregs(toks[0]) if toks and op.startswith(("ds_read", "ds_load", "ds_bpermute", "ds_permute", "ds_swizzle")) else set()
+            # (its own destination may be one that is still pending: LDS returns in order, the later write wins; its ADDRESS must not be pending)
+            if (named - dst) & busy:
+                return "LDS access uses a register whose LDS read has not been waited for: " + ins
+            pending.append(dst)
+            continue
+        if named & busy:
+            return "register of an LDS read that has not been waited for is used: " + ins
+    return None
 
 
 if __name__ == "__main__":

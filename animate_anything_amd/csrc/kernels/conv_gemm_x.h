@@ -104,8 +104,26 @@ __global__ void __launch_bounds__(64 * WM * WN, (PER_CU * WM * WN + 3) / 4) conv
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tile_m = logical / tiles_n;
-    const int tile_n = logical - tile_m * tiles_n;
+    // An XCD walks a contiguous range of `logical`.  Row-major order made its 32 resident tiles 32 COLUMN tiles of one row tile: the row tile's
+    // activations were shared, but 32 different weight tiles streamed through its 4-MB L2 per round (the 16x16-level GEGLU, 34 x 40 tiles of
+    // 256 x 256, K = 1280: 1040 MB of fabric traffic per call against 138 MB of operands, profiles/r06l_traffic_by_shape.json).  Grouped order
+    // (panels of `gm` row tiles, column by column inside a panel): the resident tiles form a gm x (32 / gm) block, the gm activation tiles of the
+    // panel stay in L2 while it sweeps the columns, and every weight tile is fetched once per panel and shared by gm workgroups.  gm from the
+    // bytes of a row tile's activations (<= ~2.5 MB per panel, <= 8), and only for WIDE outputs (>= 8 column tiles): with a few column tiles the whole
+    // weight matrix sits in L2 and row-major already streams the activations once - grouping measured +10-15 % fabric traffic there
+    // (profiles/r06m_traffic_by_shape_grouped_everywhere.json).  AaConvGemm.debug bit 4 (16): row-major everywhere (A/B).
+    int tile_m, tile_n;
+    {
+        const int tiles_m = nwg / tiles_n;
+        const int a_tile_bytes = BM * (p.c0 + p.c1) * 2;
+        int gm = ((p.debug & 16) || tiles_n < 8) ? 1 : min(8, max(1, (5 << 19) / a_tile_bytes));
+        gm = min(gm, tiles_m);
+        const int panel = gm * tiles_n, pidx = logical / panel;
+        const int rows_here = min(gm, tiles_m - pidx * gm);
+        const int within = logical - pidx * panel;
+        tile_n = within / rows_here;
+        tile_m = pidx * gm + (within - tile_n * rows_here);
+    }
 
     // debug bit 8 (scripts/phase_probe_x.py): thread 0 leaves stamps in workspace[bid][8]: shader clock at entry (0), before the
     // first DMA piece (1), with the first stage landed (6), behind the K loop (2), at exit (5); 100 MHz wall clock at entry (7) and

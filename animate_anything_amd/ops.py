@@ -51,7 +51,7 @@ K_SPLITS = 0          # tests: explicit K split count for calls that are not aut
 # not faster than partials + reduce launch (the autotuner moved the 8x8-level shapes to the compiled tile + reduce launch; step 62.5 ms
 # with, 61.9 ms without) - the release / acquire fences around the ticket write back and invalidate the XCD's L2.  Off unless asked for.
 USE_TICKETS = os.environ.get("AA_TICKETS", "0") == "1"
-DEBUG_ABLATE = 0      # profiling only: forwarded to AaConvGemm.debug
+DEBUG_ABLATE = int(os.environ.get("AA_DEBUG_ABLATE", "0"))      # profiling only: forwarded to AaConvGemm.debug (16: row-major tile order, A/B of the grouped order)
 class _TileTable:
     """The library's tile table (aa_conv_gemm_tile_info), read on first use: entries (rows, columns, K step, stages)."""
 

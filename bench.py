@@ -229,7 +229,7 @@ def write_launch_list(path, unet, one_step):
     output (+ residual)) - the per-dispatch rows of a rocprofv3 PMC pass of the same command are joined with this list
     (scripts/pmc_traffic_report.py: measured / algorithmic bytes PER SHAPE)."""
     import ctypes as C
-    from animate_anything_amd import _lib
+    from animate_anything_amd import _lib, ops
     lib = _lib.get()
     unet.enable_graph(False)
     ops.TRACE = []

@@ -89,7 +89,8 @@ typedef struct AaConvGemm {
     int32_t k_order;       /* 0: packed K is (tap, channel); 1: (64-channel chunk, tap, channel) - LDS-DMA path only */
     int32_t debug;         /* 0 in production.  Ablation bits for profiling: 1 = skip operand DMA after the first tile,
                               2 = skip the MFMA phase (results are garbage); 4 = size the
-                              round-splitting heuristic for a 2-CU chip (exercises it on small test shapes) */
+                              round-splitting heuristic for a 2-CU chip (exercises it on small test shapes);
+                              16 = row-major tile order inside an XCD's range instead of the grouped one (A/B of round 6) */
     int32_t tile;          /* -1: library picks the tile shape; >= 0: index into the tile table (autotuning) */
     int32_t k_splits;      /* 0: library decides whether to split K; >= 1: this many K ranges (needs the workspace
                               aa_conv_gemm_workspace reports for the same descriptor; ignored when not applicable) */
