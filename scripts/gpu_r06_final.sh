@@ -1,0 +1,65 @@
+#!/bin/bash
+# round 6 closing run: tile choices re-tuned from scratch for the main workload (the grouped tile order and the fused kernels changed what the
+# contractions compete with), incrementally for the other workloads; the whole GPU suite on those choices, smoke, bench lines, rocprof stats (eager)
+# + kernel trace of replayed steps, PMC traffic (per family and per shape, tied to this library's source hash), matrix-pipe counters
+OUT=gpurun_out/${1:-r06z}
+mkdir -p $OUT
+export TMPDIR=/tmp
+TC=$OUT/tile_cache.json
+timeout 2400 python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-tile-cache --tile-cache $TC > $OUT/tune_unet3d.log 2>&1; echo "tune unet3d rc=$?" >> $OUT/summary.log
+python - <<PY
+import json
+new = json.load(open("$TC")); old = json.load(open("animate_anything_amd/tile_cache_gfx950.json"))
+# keep the committed choices of signatures this run did not see (other workloads) when they were made for the same tile table; the fresh ones win
+fresh = {json.dumps(k): v for k, v in new["choices"]}
+kept = {json.dumps(k): v for k, v in old.get("choices", [])} if old.get("id") == new.get("id") else {}
+kept.update(fresh)
+new["choices"] = [[json.loads(k), v] for k, v in sorted(kept.items())]
+json.dump(new, open("$TC", "w"))
+print("tile cache: %d fresh + %d kept" % (len(fresh), len(kept) - len(fresh)))
+PY
+timeout 1500 python bench.py --workload svd --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --tile-cache $TC > $OUT/tune_svd.log 2>&1; echo "tune svd rc=$?" >> $OUT/summary.log
+timeout 1500 python bench.py --workload rgba --steps 3 --warmup 2 --no-cpu-baseline --tile-cache $TC > $OUT/tune_rgba.log 2>&1; echo "tune rgba rc=$?" >> $OUT/summary.log
+timeout 1500 python bench.py --dtype bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-other-form --no-vae --tile-cache $TC > $OUT/tune_bf16.log 2>&1; echo "tune bf16 rc=$?" >> $OUT/summary.log
+cp $TC animate_anything_amd/tile_cache_gfx950.json
+AA_PARITY_REPORT=$PWD/$OUT/parity_3steps.txt AA_PARITY_REPORT_8=$PWD/$OUT/parity_8steps.txt timeout 3000 python -m pytest tests -m gpu -x -q -n 3 > $OUT/gpu_tests.log 2>&1; echo "gpu tests rc=$?" >> $OUT/summary.log
+tail -3 $OUT/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.log
+tail -1 $OUT/smoke.log
+timeout 900 python bench.py --gemm-breakdown $OUT/gemm_breakdown.txt > $OUT/bench.json 2>$OUT/bench.err; echo "bench rc=$?" >> $OUT/summary.log
+timeout 900 python bench.py --workload svd --gemm-breakdown $OUT/svd_gemm_breakdown.txt > $OUT/bench_svd.json 2>$OUT/bench_svd.err; echo "bench svd rc=$?" >> $OUT/summary.log
+timeout 900 python bench.py --workload rgba > $OUT/bench_rgba.json 2>$OUT/bench_rgba.err; echo "bench rgba rc=$?" >> $OUT/summary.log
+timeout 900 python bench.py --dtype bf16 --no-cpu-baseline --no-other-form > $OUT/bench_bf16.json 2>/dev/null; echo "bench bf16 rc=$?" >> $OUT/summary.log
+for knob in "AA_SEQ_ATTN=0" "AA_FF_FUSED=0" "AA_DEBUG_ABLATE=16" "AA_SEQ_ATTN=0 AA_FF_FUSED=0 AA_DEBUG_ABLATE=16"; do
+  tag=$(echo $knob | tr ' =' '__')
+  env $knob timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-vae --no-other-form --no-roofline --tile-cache $OUT/tc_$tag.json > /dev/null 2>&1
+  for rep in 1 2; do
+    env $knob timeout 600 python bench.py --no-cpu-baseline --no-vae --no-other-form --no-roofline --tile-cache $OUT/tc_$tag.json > $OUT/ab_${tag}_$rep.json 2>/dev/null
+    timeout 600 python bench.py --no-cpu-baseline --no-vae --no-other-form --no-roofline > $OUT/ab_default_${tag}_$rep.json 2>/dev/null
+  done
+done
+ROOT=$PWD
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o p -- python $ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --no-other-form --no-vae > $ROOT/$OUT/prof.log 2>&1; echo "rocprof rc=$?" >> $ROOT/$OUT/summary.log
+cd $ROOT
+find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+find $OUT/prof -name "*kernel_trace.csv" -delete
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/gprof -o g -- python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-other-form --no-vae > $ROOT/$OUT/gprof.log 2>&1; echo "graph trace rc=$?" >> $ROOT/$OUT/summary.log
+cd $ROOT
+python scripts/gap_report.py $OUT/gprof > $OUT/graph_step_kernels.txt 2>&1
+find $OUT/gprof -name "*kernel_trace.csv" -delete
+bash scripts/pmc_traffic.sh ${1:-r06z}/traffic > $OUT/traffic.log 2>&1
+bash scripts/pmc_step_sq.sh ${1:-r06z}/sq > $OUT/sq.log 2>&1
+rocm-smi --showclocks --showpower 2>/dev/null | head -20 > $OUT/smi.txt
+cat $OUT/summary.log
+cat $OUT/bench.json | cut -c1-2600
+cat $OUT/bench_svd.json | cut -c1-400
+cat $OUT/bench_rgba.json | cut -c1-400
+cat $OUT/bench_bf16.json | cut -c1-300
+for f in $OUT/ab_*.json; do python -c "
+import json,sys; d=json.load(open('$f')); print('$f', d['ms_per_step'], d['autotuned_signatures'])"; done
+head -16 $OUT/kernel_stats.csv | cut -c1-160
+grep -A20 "by kernel family" $OUT/graph_step_kernels.txt
+cat gpurun_out/${1:-r06z}/traffic/traffic.json | head -30
+tail -20 $OUT/sq.log

@@ -14,6 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(args, env_extra, timeout=600, script="tests/bench_selftest.py"):
+    # the ranks load the suite's CPU build of the kernels: bring it up to date HERE, once - two ranks rebuilding a stale library at the same
+    # time race on the file (one rank dlopens while the other relinks)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    build_emu.build()
     env = dict(os.environ, AA_EMU_THREADS="2", OMP_NUM_THREADS="2", **env_extra)
     return subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, capture_output=True, text=True, env=env,
                           timeout=timeout, cwd=ROOT)
