@@ -74,6 +74,15 @@ class AaFFFused(C.Structure):
     ]
 
 
+class AaLinearRows(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p), ("w", C.c_void_p), ("rows", C.c_int64),
+        ("channels", C.c_int32), ("n_out", C.c_int32), ("ldx", C.c_int32), ("ld_res", C.c_int32), ("ldo", C.c_int32),
+        ("normalize", C.c_int32), ("ln_eps", C.c_float), ("dtype", C.c_int32), ("flags", C.c_int32),
+        ("row_affine", C.c_void_p), ("rows_per_group", C.c_int32), ("_pad", C.c_int32),
+    ]
+
+
 class AaDpmStep(C.Structure):
     _fields_ = [
         ("eps_uncond", C.c_void_p), ("eps_text", C.c_void_p), ("latents", C.c_void_p), ("x0_prev", C.c_void_p),
@@ -127,8 +136,8 @@ class AaEulerStepTok(C.Structure):
     ]
 
 
-SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_conv_gemm_row_stats_parts", "aa_conv_gemm_row_coef_ok", "aa_conv_gemm_tickets", "aa_conv_gemm_reduce_launches", "aa_conv_gemm_tile_flags", "aa_ln_finalize", "aa_groupnorm_workspace", "aa_groupnorm", "aa_set_groupnorm_two_pass", "aa_groupnorm_plan",
-           "aa_layernorm", "aa_attention", "aa_seq_self_attention_ok", "aa_seq_self_attention", "aa_ff_fused_ok", "aa_ff_fused", "aa_softmax_rows", "aa_cfg_dpm_step",
+SYMBOLS = ("aa_version", "aa_last_error", "aa_set_tile_override", "aa_conv_gemm_tile_info", "aa_conv_gemm_tile_ok", "aa_conv_gemm_workspace", "aa_conv_gemm", "aa_conv_gemm_launch_count", "aa_conv_gemm_row_stats_parts", "aa_conv_gemm_row_coef_ok", "aa_conv_gemm_tickets", "aa_conv_gemm_reduce_launches", "aa_conv_gemm_tile_flags", "aa_ln_finalize", "aa_groupnorm_workspace", "aa_groupnorm", "aa_groupnorm_coef", "aa_set_groupnorm_two_pass", "aa_groupnorm_plan",
+           "aa_layernorm", "aa_attention", "aa_seq_self_attention_ok", "aa_seq_self_attention", "aa_ff_fused_ok", "aa_ff_fused", "aa_linear_rows_ok", "aa_linear_rows", "aa_softmax_rows", "aa_cfg_dpm_step",
            "aa_timestep_embedding", "aa_pack_latents", "aa_cfg_dpm_step_tokens",
            "aa_blend", "aa_pack_frames", "aa_cfg_euler_step_tokens")
 
@@ -179,6 +188,9 @@ def bind(path: str) -> C.CDLL:
     lib.aa_seq_self_attention.argtypes = [C.POINTER(AaSeqSelfAttn), C.c_void_p]
     lib.aa_ff_fused_ok.argtypes = [C.POINTER(AaFFFused)]
     lib.aa_ff_fused.argtypes = [C.POINTER(AaFFFused), C.c_void_p]
+    lib.aa_groupnorm_coef.argtypes = [C.POINTER(AaGroupNorm), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.aa_linear_rows_ok.argtypes = [C.POINTER(AaLinearRows)]
+    lib.aa_linear_rows.argtypes = [C.POINTER(AaLinearRows), C.c_void_p]
     lib.aa_softmax_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.aa_cfg_dpm_step.argtypes = [C.POINTER(AaDpmStep), C.c_void_p]
     lib.aa_timestep_embedding.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]

@@ -64,7 +64,7 @@ def build(force=False, verbose=False, probe=False, ablate=0, variant=None):
     # attention / norm / glue kernels' headers through aa_api_impl.h but instantiate nothing of them (AA_TU_TILES_ONLY), so edits
     # there rebuild the C-ABI unit alone (~1.5 of the ~4 minutes).  Key = sha256 of (flags, the unit's sources).
     import hashlib
-    api_only = {"attention.h", "seq_attention.h", "norm.h", "glue.h"}
+    api_only = {"attention.h", "seq_attention.h", "norm.h", "glue.h", "ff_fused.h", "linear_rows.h"}
 
     def dep_hash(job):
         src, _ = job
@@ -182,7 +182,7 @@ def audit_x_kernels(lib_path):
     # the one-wave-per-SIMD FeedForward kernel lives at the edge of the register file too: no scratch, no spills (its ablation instantiations
     # are profiling code and exempt)
     for k, (_agpr, scratch, _vgpr, spills) in sorted(meta.items()):
-        if "ff_fused_kernel" in k and "ELi0EEE" in k and (scratch or spills):
+        if ("ff_fused_kernel" in k and "ELi0EEE" in k or "linear_rows_kernel" in k) and (scratch or spills):
             problems.append(f"{k}: scratch {scratch} bytes, {spills} VGPR spills in a hot kernel")
     xk = {k: v for k, v in meta.items() if "conv_gemm_x_kernel" in k}
     if len(xk) < 16:                                        # 8 tiles x {fp16, bf16} at the very least
@@ -201,7 +201,7 @@ def audit_x_kernels(lib_path):
     # order, `s_waitcnt lgkmcnt(N)` leaves at most N of them pending (scalar loads also count in the hardware counter: ignoring them is the
     # conservative reading).
     for name in sorted(bodies):
-        if not any(t in name for t in ("attention_kernel", "attention_shortkv_kernel", "ff_fused_kernel")):
+        if not any(t in name for t in ("attention_kernel", "attention_shortkv_kernel", "ff_fused_kernel", "linear_rows_kernel")):
             continue
         hit = pending_lds_read_violation(bodies[name])
         if hit:

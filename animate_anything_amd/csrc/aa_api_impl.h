@@ -16,6 +16,7 @@
 #include "kernels/attention.h"
 #include "kernels/seq_attention.h"
 #include "kernels/ff_fused.h"
+#include "kernels/linear_rows.h"
 #include "kernels/glue.h"
 
 namespace aa {
@@ -726,6 +727,31 @@ int aa_groupnorm(const AaGroupNorm* d, void* workspace, size_t workspace_bytes, 
     return groupnorm_t<bf16_t>(*d, (float*)workspace, chunks, chunks, stream);
 }
 
+int aa_groupnorm_coef(const AaGroupNorm* d, void* workspace, size_t workspace_bytes, float* coef, void* stream) {
+    using namespace aa;
+    if (!d || !coef) return fail(AA_E_SHAPE, "groupnorm_coef: null descriptor / coef");
+    const int C = d->c0 + d->c1;
+    if (d->c0 <= 0 || d->c0 % 8 || d->c1 % 8 || d->num_groups <= 0 || C % d->num_groups || d->num_groups > GN_THREADS)
+        return fail(AA_E_SHAPE, "groupnorm_coef: bad channels c0=%d c1=%d groups=%d", d->c0, d->c1, d->num_groups);
+    if (d->n_groups_img <= 0 || d->tokens_per_group <= 0) return fail(AA_E_SHAPE, "groupnorm_coef: bad token geometry");
+    if (d->silu) return fail(AA_E_SHAPE, "groupnorm_coef: a norm with SiLU behind it is not affine");
+    if (!aligned16(d->x0) || !aligned16(d->x1) || !aligned16(coef)) return fail(AA_E_ALIGN, "groupnorm_coef: operands must be 16-byte aligned");
+    const size_t need = aa_groupnorm_workspace(d);
+    if (!workspace || workspace_bytes < need) return fail(AA_E_WORKSPACE, "groupnorm_coef: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (d->dtype != AA_F16 && d->dtype != AA_BF16) return fail(AA_E_DTYPE, "groupnorm_coef: unsupported dtype %d", d->dtype);
+    const int chunks = gn_chunks(*d), S = C / 8, rpp = S <= GN_THREADS ? GN_THREADS / S : 1;
+    const size_t lds = (size_t)2 * (GN_THREADS + d->num_groups) * 4;
+    float* ws = (float*)workspace;
+    if (d->dtype == AA_F16) {
+        AA_LAUNCH((groupnorm_stats_kernel<f16_t>), dim3(chunks, d->n_groups_img), dim3(GN_THREADS), (size_t)C * 8 * (1 + rpp), stream, *d, ws, chunks);
+        AA_LAUNCH((groupnorm_coef_kernel<f16_t>), dim3(d->n_groups_img), dim3(GN_THREADS), lds, stream, *d, (const float*)ws, chunks, coef);
+    } else {
+        AA_LAUNCH((groupnorm_stats_kernel<bf16_t>), dim3(chunks, d->n_groups_img), dim3(GN_THREADS), (size_t)C * 8 * (1 + rpp), stream, *d, ws, chunks);
+        AA_LAUNCH((groupnorm_coef_kernel<bf16_t>), dim3(d->n_groups_img), dim3(GN_THREADS), lds, stream, *d, (const float*)ws, chunks, coef);
+    }
+    return finish("groupnorm_coef");
+}
+
 int aa_layernorm(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t channels,
                  float eps, int32_t dtype, void* stream) {
     using namespace aa;
@@ -840,6 +866,39 @@ int aa_ff_fused(const AaFFFused* d, void* stream) {
     else                    AA_LAUNCH((ff_fused_kernel<bf16_t, 320>), grid, block, ff_lds_bytes(), stream, *d);
 #undef AA_FF
     return finish("ff_fused");
+}
+
+int aa_linear_rows_ok(const AaLinearRows* d) {
+    if (!d || d->channels != 320 || d->rows <= 0 || d->n_out <= 0 || d->n_out % 32) return 0;
+    if (d->ldx % 8 || d->ldo % 8 || d->ld_res % 8 || d->ldx < d->channels || d->ldo < d->n_out || (d->residual && d->ld_res < d->n_out)) return 0;
+    const int64_t lim = (int64_t)1 << 31;
+    if (d->rows * d->ldx * 2 >= lim || d->rows * d->ldo * 2 >= lim || (d->residual && d->rows * d->ld_res * 2 >= lim)) return 0;
+    if (d->dtype != AA_F16 && d->dtype != AA_BF16) return 0;
+    if (d->row_affine && (d->rows_per_group <= 0 || d->rows_per_group % 32)) return 0;
+    return 1;
+}
+
+int aa_linear_rows(const AaLinearRows* d, void* stream) {
+    using namespace aa;
+    if (!d) return fail(AA_E_SHAPE, "linear_rows: null descriptor");
+    if (!aa_linear_rows_ok(d)) return fail(AA_E_SHAPE, "linear_rows: unsupported call (channels %d, n_out %d, rows %lld, dtype %d)", d->channels, d->n_out, (long long)d->rows, d->dtype);
+    if (!d->x || !d->out || !d->w) return fail(AA_E_SHAPE, "linear_rows: x, out, w are required");
+    if (!aligned16(d->x) || !aligned16(d->residual) || !aligned16(d->out) || !aligned16(d->w) || !aligned16(d->row_affine)) return fail(AA_E_ALIGN, "linear_rows: operands must be 16-byte aligned");
+    if (d->normalize && !(d->ln_eps > 0.0f)) return fail(AA_E_SHAPE, "linear_rows: normalize needs ln_eps > 0");
+    // Two workgroups per CU run in lock-step rounds of 512 tiles (139264 rows = 1088 tiles = 2.125 rounds: the last round would hold 64 tiles and
+    // cost as much as a full one).  The tiles behind the last full round are split over their stages - n_split workgroups of nq / n_split
+    // stages each, as many as still fit one round (flags bit 0: pretend a 2-CU chip - exercises the split in tests; bit 1: no split).
+    const int tiles = (int)((d->rows + 32 * LR_NW - 1) / (32 * LR_NW)), nq = d->n_out / 32;
+    const int slots = ((d->flags & 1) ? 2 : 256) * 2;
+    int n_full = (d->flags & 2) ? tiles : tiles / slots * slots, n_split = 1;
+    if (tiles - n_full > 0)
+        for (int s = 2; s <= nq && (tiles - n_full) * s <= slots; ++s)
+            if (nq % s == 0) n_split = s;
+    if (n_split == 1) n_full = tiles;
+    const dim3 grid((unsigned)(n_full + (tiles - n_full) * n_split)), block(64 * LR_NW);
+    if (d->dtype == AA_F16) AA_LAUNCH((linear_rows_kernel<f16_t, 320>), grid, block, lr_lds_bytes(), stream, *d, n_full, n_split);
+    else                    AA_LAUNCH((linear_rows_kernel<bf16_t, 320>), grid, block, lr_lds_bytes(), stream, *d, n_full, n_split);
+    return finish("linear_rows");
 }
 
 int aa_softmax_rows(const float* x, void* y, int64_t rows, int32_t cols, int32_t x_ld, int32_t y_ld, int32_t dtype, void* stream) {

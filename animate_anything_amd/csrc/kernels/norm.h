@@ -219,6 +219,50 @@ __global__ void __launch_bounds__(GN_THREADS) groupnorm_apply_kernel(const AaGro
     }
 }
 
+// ---- GroupNorm pass 2 WITHOUT the normalisation: the per-channel (scale, shift) of every image group as fp32 [img group][2][C] for a consumer
+// that applies them to the rows it holds anyway (aa_linear_rows: `row_affine`) - the arithmetic of groupnorm_apply_kernel's first block.
+// grid = n_groups_img.
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS) groupnorm_coef_kernel(const AaGroupNorm p, const float* partial, int chunks, float* coef) {
+    const int C = p.c0 + p.c1;
+    float* s_red = reinterpret_cast<float*>(dyn_smem());      // [lanes][num_groups][2] then [num_groups][2]
+    const int tid = threadIdx.x;
+    const int ig = blockIdx.x;
+    const int G = p.num_groups;
+    const int lanes = GN_THREADS / G;
+    const int g = tid % G, j = tid / G;
+    float a = 0.0f, b = 0.0f;
+    if (j < lanes)
+        for (int ch = j; ch < chunks; ch += lanes) {
+            const float* src = partial + (((int64_t)ig * chunks + ch) * G + g) * 2;
+            a += src[0]; b += src[1];
+        }
+    if (j < lanes) { s_red[(j * G + g) * 2] = a; s_red[(j * G + g) * 2 + 1] = b; }
+    __syncthreads();
+    if (tid < G) {
+        float sa = 0.0f, sb = 0.0f;
+        for (int jj = 0; jj < lanes; ++jj) { sa += s_red[(jj * G + tid) * 2]; sb += s_red[(jj * G + tid) * 2 + 1]; }
+        const float cnt = (float)p.tokens_per_group * (float)(C / G);
+        const float dm = sa / cnt;
+        const float var = fmaxf(sb / cnt - dm * dm, 0.0f);
+        const float mean = dm + gn_pivot<T>(reinterpret_cast<const T*>(p.x0), reinterpret_cast<const T*>(p.x1), p.c0, p.c1,
+                                            (int64_t)ig * p.tokens_per_group, tid * (C / G));
+        s_red[(lanes * G + tid) * 2] = mean;
+        s_red[(lanes * G + tid) * 2 + 1] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    const T* gamma = reinterpret_cast<const T*>(p.gamma);
+    const T* beta = reinterpret_cast<const T*>(p.beta);
+    const int cg = C / G;
+    for (int c = tid; c < C; c += GN_THREADS) {
+        const int gg = c / cg;
+        const float mean = s_red[(lanes * G + gg) * 2], rstd = s_red[(lanes * G + gg) * 2 + 1];
+        const float sc = rstd * (float)gamma[c];
+        coef[((int64_t)ig * 2 + 0) * C + c] = sc;
+        coef[((int64_t)ig * 2 + 1) * C + c] = (float)beta[c] - mean * sc;
+    }
+}
+
 // ---- GroupNorm in ONE pass over HBM: a workgroup owns `GB` channel groups (CW = GB * C/num_groups channels: a row segment of
 // CW * 2 bytes) of ALL tokens of one image group (at most rpp * NR) and keeps them in REGISTERS (NR 16-byte pieces per
 // thread; a CU's register file holds 512 KB) between the statistics and the normalisation: x is read once and y written

@@ -102,6 +102,20 @@ SEQ_PRE = os.environ.get("AA_SEQ_PRE", "0") == "1"   # measured (r06f): 214 us a
 FF_FUSED = os.environ.get("AA_FF_FUSED", "1") == "1"
 FF_SPLIT = os.environ.get("AA_FF_SPLIT", "1") == "1"
 SEQ_ATTN_CHANNELS = tuple(int(c) for c in os.environ.get("AA_SEQ_ATTN_CHANNELS", "320,512").split(",") if c)
+# The K = C projections of the 320-channel transformers (proj_in, to_q, to_out + residual, the Q|K|V of the spatial self-attention) with the token
+# rows in registers (ops.linear_rows, ABI 109) instead of tiles of the contraction family: the rows are normalised in the registers, so the
+# producers in front emit no row statistics.  AA_LINEAR_ROWS=0: the contractions (LayerNorm folded from producer-written coefficients).
+LINEAR_ROWS = os.environ.get("AA_LINEAR_ROWS", "1") == "1"
+# ... and the GroupNorm in front of proj_in (affine-only: no SiLU behind it) applied to the rows in those registers: its statistics pass runs alone
+# (ops.groupnorm_coef), the normalised tensor is never written (AA_GN_FOLD=0: the statistics + normalise pair in front of proj_in).
+GN_FOLD = os.environ.get("AA_GN_FOLD", "1") == "1"
+LINEAR_ROWS_MIN = 16384              # below: a handful of 128-row workgroups that walk all output channels serially - the tile family is faster
+
+
+def rows_path(channels, n_out, rows, dtype):
+    return LINEAR_ROWS and rows >= LINEAR_ROWS_MIN and ops.linear_rows_ok(channels, n_out, rows, dtype)
+
+
 UPSAMPLE_AS_PARITY_CONVS = True      # Upsample2D at exactly x2: four 2x2 convolutions (ops.pack_upsample2x_weights); False = the 3x3 gather form
 
 
@@ -113,8 +127,27 @@ class Linear(_Packed, nn.Linear):
     _sp = None
     _sp_key = None
 
-    def tokens(self, x, **epilogue):
+    _rp = None
+    _rp_key = None
+
+    def rows_packed(self):
+        """This layer as the weight stream of ops.linear_rows, cached."""
+        key = weights_key(self.weight, self.bias)
+        if self._rp is None or self._rp_key != key:
+            self._rp, self._rp_key = ops.pack_linear_rows(self.weight, self.bias), key
+        return self._rp
+
+    def tokens(self, x, affine=None, **epilogue):
+        """`affine` = (ops.groupnorm_coef(...), rows per image group) of the GroupNorm in front (caller checked norm_rows_ok): x is the un-normalised tensor."""
+        if affine is not None or (not epilogue.get("row_stats") and not (set(epilogue) - {"residual", "row_stats", "coef_eps"}) and x.dim() == 2
+                                  and x.stride(1) == 1 and rows_path(self.in_features, self.out_features, x.shape[0], x.dtype) and x.shape[1] == self.in_features):
+            return ops.linear_rows(x, self.rows_packed(), epilogue.get("residual"), affine=affine)
         return ops.conv_gemm(x, self.packed(), ops.linear_geom(x.shape[0]), **epilogue)
+
+    def norm_rows_ok(self, x, tokens_per_group):
+        """Can a GroupNorm in front of this layer be applied inside it (ops.linear_rows(affine=...): its normalisation pass is never run)?"""
+        return GN_FOLD and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == self.in_features and \
+            rows_path(self.in_features, self.out_features, x.shape[0], x.dtype) and ops.linear_rows_ok(self.in_features, self.out_features, x.shape[0], x.dtype, tokens_per_group)
 
     def seq_pre(self):
         """This layer as the projection run inside ops.seq_self_attention in front of the normalisation (ops.pack_seq_pre), cached."""
@@ -125,6 +158,7 @@ class Linear(_Packed, nn.Linear):
 
     def _apply(self, fn, *a, **k):
         self._sp = None
+        self._rp = None
         return super()._apply(fn, *a, **k)
 
     def forward(self, x):
@@ -148,6 +182,10 @@ class Conv3d(_Packed, nn.Conv3d):
 
 
 class GroupNorm(nn.GroupNorm):
+    def coef_tokens(self, x, n_stat_groups, tokens_per_group):
+        """The statistics alone, as per-channel (scale, shift) of every image group (ops.groupnorm_coef): the consumer normalises."""
+        return ops.groupnorm_coef(x, self.weight, self.bias, n_stat_groups, tokens_per_group, self.num_groups, self.eps)
+
     def tokens(self, x, n_stat_groups, tokens_per_group, silu=False, x1=None, out=None):
         return ops.groupnorm(x, self.weight, self.bias, n_stat_groups, tokens_per_group, self.num_groups,
                              self.eps, silu, x1=x1, out=out)
@@ -317,6 +355,7 @@ class Attention(nn.Module):
     def _apply(self, fn, *a, **k):
         self._fused = None
         self._fused_ln = None
+        self._rows_ln = None
         self._seq_w = None
         return super()._apply(fn, *a, **k)
 
@@ -337,6 +376,22 @@ class Attention(nn.Module):
             self._fused_ln_key = key
         return self._fused_ln
 
+    def rows_ln(self, norm):
+        """fused_ln(norm) as the weight stream of ops.linear_rows (the rows are normalised inside the kernel)."""
+        rows = [self.to_q.weight] if self.is_cross else [self.to_q.weight, self.to_k.weight, self.to_v.weight]
+        key = weights_key(*rows, norm.weight, norm.bias)
+        if self._rows_ln is None or self._rows_ln_key != key:
+            self._rows_ln = ops.pack_linear_rows(torch.cat([r.detach() for r in rows], dim=0), None, ln=(norm.weight, norm.bias, norm.eps))
+            self._rows_ln_key = key
+        return self._rows_ln
+
+    def rows_ok(self, x):
+        """Does the projection behind the LayerNorm in front of this layer (Q|K|V, or Q of a cross-attention) run on ops.linear_rows?"""
+        return self.to_q.bias is None and x.dim() == 2 and x.stride(1) == 1 and \
+            rows_path(self.to_q.in_features, self.inner * (1 if self.is_cross else 3), x.shape[0], x.dtype)
+
+    _rows_ln = None
+    _rows_ln_key = None
     _fused_ln = None
     _fused_ln_key = None
     _seq_w = None
@@ -375,7 +430,7 @@ class Attention(nn.Module):
         kv = self.text_kv(text_tokens)
         return self.to_out[0].tokens(kv[:, self.inner:].contiguous())
 
-    def self_tokens(self, normed, residual, g: Grid, temporal: bool, ln=None, seq_ln=None, **epilogue):
+    def self_tokens(self, normed, residual, g: Grid, temporal: bool, ln=None, seq_ln=None, rows_ln=None, **epilogue):
         """`ln` = (LayerNorm module, ops.RowStats of `normed`'s rows): `normed` is then the UN-normalised tensor and the
         LayerNorm is folded into the Q|K|V projection.  `row_stats=True` (epilogue) returns (out, RowStats or None).
         `seq_ln` = the LayerNorm module in front (caller checked seq_ok): `normed` is the un-normalised tensor; LayerNorm, Q|K|V
@@ -383,7 +438,9 @@ class Attention(nn.Module):
         if seq_ln is not None:
             a = self.seq_attention(normed, seq_ln, g)
             return self.to_out[0].tokens(a, residual=residual, **epilogue)
-        if ln is None:
+        if rows_ln is not None:                           # (the LayerNorm module in front, caller checked rows_ok: `normed` is the un-normalised tensor)
+            qkv = ops.linear_rows(normed, self.rows_ln(rows_ln))
+        elif ln is None:
             qkv = ops.conv_gemm(normed, self.fused(), ops.linear_geom(normed.shape[0]))
         else:
             qkv = ops.conv_gemm(normed, self.fused_ln(ln[0]), ops.linear_geom(normed.shape[0]), ln_stats=ln[1])
@@ -396,8 +453,10 @@ class Attention(nn.Module):
             a = ops.attention(qkv, 0, qkv, c, qkv, 2 * c, self.heads, g.images, 1, g.hw, g.hw, st, st)
         return self.to_out[0].tokens(a, residual=residual, **epilogue)
 
-    def cross_tokens(self, normed, residual, g: Grid, kv, kv_len, ln=None, **epilogue):
-        if ln is None:
+    def cross_tokens(self, normed, residual, g: Grid, kv, kv_len, ln=None, rows_ln=None, **epilogue):
+        if rows_ln is not None:                           # (see self_tokens)
+            q = ops.linear_rows(normed, self.rows_ln(rows_ln))
+        elif ln is None:
             q = self.to_q.tokens(normed)
         else:                                             # (see self_tokens)
             q = ops.conv_gemm(normed, self.fused_ln(ln[0]), ops.linear_geom(normed.shape[0]), ln_stats=ln[1])
@@ -527,9 +586,16 @@ class BasicTransformerBlock(nn.Module):
             return self.ff.tokens(self.norm3.tokens(x), residual=x, tail=tail)
         if pre_in is not None:
             raise RuntimeError("BasicTransformerBlock: `pre_in` needs both attention layers on the fused path")
+        rows1 = not seq1 and self.attn1.rows_ok(x)        # norm1 / norm2 inside the projection behind them (ops.linear_rows): no statistics from the producers
+        rows2 = not seq2 and x.shape[1] == self.attn2.to_q.in_features and \
+            rows_path(x.shape[1], self.attn2.inner * (1 if self.attn2.is_cross else 3), x.shape[0] * dup, x.dtype) and self.attn2.to_q.bias is None
         if seq1:                                          # norm1 + Q|K|V + attention in one kernel; norm2's statistics only if its consumer folds it
             want = fold and not seq2
             r = self.attn1.self_tokens(x, x, g, temporal, seq_ln=self.norm1, row_stats=want, coef_eps=self.norm2.eps)
+            x, st = r if want else (r, None)
+        elif rows1:
+            want = fold and not rows2
+            r = self.attn1.self_tokens(x, x, g, temporal, rows_ln=self.norm1, row_stats=want, coef_eps=self.norm2.eps)
             x, st = r if want else (r, None)
         elif fold and x_stats is not None:
             x, st = self.attn1.self_tokens(x, x, g, temporal, ln=(self.norm1, x_stats), row_stats=True, coef_eps=self.norm2.eps)
@@ -543,13 +609,14 @@ class BasicTransformerBlock(nn.Module):
         if seq2:
             r = self.attn2.self_tokens(x, x, g, temporal, seq_ln=self.norm2, row_stats=fold_ff, coef_eps=self.norm3.eps)
         else:
-            ln2 = None if st is None else (self.norm2, st)
-            xin = x if ln2 is not None else self.norm2.tokens(x)
+            rows2 = rows2 and self.attn2.rows_ok(x)
+            ln2 = None if st is None or rows2 else (self.norm2, st)
+            xin = x if ln2 is not None or rows2 else self.norm2.tokens(x)
             if self.attn2.is_cross:
                 kv = self.attn2.text_kv(text)
-                r = self.attn2.cross_tokens(xin, x, g, kv, text_len, ln=ln2, row_stats=fold_ff, coef_eps=self.norm3.eps)
+                r = self.attn2.cross_tokens(xin, x, g, kv, text_len, ln=ln2, rows_ln=self.norm2 if rows2 else None, row_stats=fold_ff, coef_eps=self.norm3.eps)
             else:
-                r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, row_stats=fold_ff, coef_eps=self.norm3.eps)
+                r = self.attn2.self_tokens(xin, x, g, temporal, ln=ln2, rows_ln=self.norm2 if rows2 else None, row_stats=fold_ff, coef_eps=self.norm3.eps)
         x, st = r if fold_ff else (r, None)
         if ff_one:
             return self.ff.fused_tokens(x, self.norm3, tail)
@@ -624,8 +691,13 @@ class Transformer2DModel(_MergedTail, nn.Module):
 
     def tokens(self, x, g: Grid, text, text_len, dup: int = 1):
         """`dup` > 1 (see BasicTransformerBlock.tokens): x / g are the single copy, the result covers all `dup` groups."""
-        h, st = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw), row_stats=True, coef_eps=self.transformer_blocks[0].norm1.eps) if LN_FOLD else \
-                (self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw)), None)
+        blk0 = self.transformer_blocks[0]
+        want = LN_FOLD and not (blk0.attn1.to_q.bias is None and rows_path(self.proj_in.out_features, 3 * blk0.attn1.inner, x.shape[0], x.dtype))
+        if not want and self.proj_in.norm_rows_ok(x, g.hw):
+            h, st = self.proj_in.tokens(x, affine=(self.norm.coef_tokens(x, g.images, g.hw), g.hw)), None
+        else:
+            h, st = self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw), row_stats=True, coef_eps=blk0.norm1.eps) if want else \
+                    (self.proj_in.tokens(self.norm.tokens(x, g.images, g.hw)), None)
         outer = torch.cat([x] * dup) if dup > 1 else x
         mt, last = self.merged_tail(), len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
@@ -654,14 +726,18 @@ class TransformerTemporalModel(_MergedTail, nn.Module):
         # (norm1's statistics are only wanted when the first attention layer folds it: ops.seq_self_attention normalises in its registers)
         want = LN_FOLD and not (SEQ_ATTN and blk0.attn1.inner in SEQ_ATTN_CHANNELS and blk0.attn1.dim_head == 64 and self.proj_in.out_features == blk0.attn1.inner
                                 and ops.seq_self_attention_ok(blk0.attn1.inner, g.frames, x.shape[0], x.dtype))
-        xn = self.norm.tokens(x, g.clips, g.frames * g.hw)
+        fold_norm = not want and not SEQ_PRE and self.proj_in.norm_rows_ok(x, g.frames * g.hw)
+        xn = None if fold_norm else self.norm.tokens(x, g.clips, g.frames * g.hw)
         mt, last = self.merged_tail(), len(self.transformer_blocks) - 1
-        if blk0.seq_pair_ok(xn, g, True) and self.proj_in.out_features == self.proj_in.in_features == blk0.attn1.inner:
+        if xn is not None and blk0.seq_pair_ok(xn, g, True) and self.proj_in.out_features == self.proj_in.in_features == blk0.attn1.inner:
             h = xn                                        # proj_in runs inside the first attention kernel
             for i, blk in enumerate(self.transformer_blocks):
                 h = blk.tokens(h, g, temporal=True, tail=(mt, x, self.fused_ff()) if mt is not None and i == last else None, pre_in=self.proj_in if i == 0 else None)
             return h if mt is not None else self.proj_out.tokens(h, residual=x)
-        h, st = self.proj_in.tokens(xn, row_stats=True, coef_eps=blk0.norm1.eps) if want else (self.proj_in.tokens(xn), None)
+        if fold_norm:
+            h, st = self.proj_in.tokens(x, affine=(self.norm.coef_tokens(x, g.clips, g.frames * g.hw), g.frames * g.hw)), None
+        else:
+            h, st = self.proj_in.tokens(xn, row_stats=True, coef_eps=blk0.norm1.eps) if want else (self.proj_in.tokens(xn), None)
         for i, blk in enumerate(self.transformer_blocks):
             h = blk.tokens(h, g, temporal=True, x_stats=st if i == 0 else None, tail=(mt, x, self.fused_ff()) if mt is not None and i == last else None)
         return h if mt is not None else self.proj_out.tokens(h, residual=x)

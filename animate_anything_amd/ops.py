@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (AA_ACT_GELU, AA_ACT_NONE, AA_ACT_QUICK_GELU, AA_ACT_SILU, AA_BF16, AA_F16, AA_F32, AaAttention, AaAttnOperand,
-                   AaBlend, AaConvGemm, AaFFFused, AaDpmStep, AaDpmStepTok, AaEulerStepTok, AaGroupNorm, AaPackFrames, AaPackLatents, AaSeqSelfAttn)
+                   AaBlend, AaConvGemm, AaFFFused, AaLinearRows, AaDpmStep, AaDpmStepTok, AaEulerStepTok, AaGroupNorm, AaPackFrames, AaPackLatents, AaSeqSelfAttn)
 
 _DT = {torch.float16: AA_F16, torch.bfloat16: AA_BF16, torch.float32: AA_F32}
 
@@ -682,6 +682,25 @@ def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_group
     return y
 
 
+def groupnorm_coef(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_groups_img: int, tokens_per_group: int, num_groups: int = 32,
+                   eps: float = 1e-5) -> torch.Tensor:
+    """The statistics pass of `groupnorm` alone: fp32 [n_groups_img, 2, C] = per-channel (scale, shift) of every image group, for
+    linear_rows(affine=...) - the normalised tensor is never written."""
+    lib = _lib.get()
+    _check(x0, gamma, beta)
+    c0 = x0.shape[-1]
+    d = AaGroupNorm()
+    d.x0, d.x1, d.gamma, d.beta, d.y = _ptr(x0), None, _ptr(gamma), _ptr(beta), None
+    d.c0, d.c1 = c0, 0
+    d.n_groups_img, d.tokens_per_group, d.num_groups = n_groups_img, tokens_per_group, num_groups
+    d.silu, d.dtype, d.eps = 0, _DT[x0.dtype], eps
+    nbytes = lib.aa_groupnorm_workspace(C.byref(d))
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x0.device)
+    coef = torch.empty(n_groups_img, 2, c0, dtype=torch.float32, device=x0.device)
+    _run(lib.aa_groupnorm_coef, C.byref(d), _ptr(ws), nbytes, _ptr(coef), _stream(x0))
+    return coef
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     lib = _lib.get()
     _check(x, gamma, beta)
@@ -953,6 +972,82 @@ def ff_fused(x: torch.Tensor, pk: FFFused, outer: Optional[torch.Tensor] = None,
         raise RuntimeError("ff_fused: `out` must have x's shape and dtype")
     d = _ff_fused_desc(x, pk, outer, out)
     _run(lib.aa_ff_fused, C.byref(d), _stream(x))
+    return out
+
+
+# ------------------------------------------------------------------------------------- K = C projections with the rows in registers
+LR_STAGE_BYTES = 21504                          # include/aa_mi355.h: AA_LR_STAGE_BYTES
+LINEAR_ROWS_DEBUG = int(os.environ.get("AA_LINEAR_ROWS_DEBUG", "0"))      # AaLinearRows.flags (1: plan for a 2-CU chip, 2: no stage split of the last round)
+
+
+@dataclass
+class LinearRows:
+    """Operand of aa_linear_rows: `w` = the weight stream [n_out / 32, 21504 / 2] of the storage type (see pack_linear_rows)."""
+    w: torch.Tensor
+    n_out: int
+    ln_eps: float
+    normalize: bool
+
+
+def pack_linear_rows(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, ln=None) -> LinearRows:
+    """nn.Linear(320, n_out) [+ the LayerNorm (gamma, beta, eps) in front of it] -> the weight stream of linear_rows: per 32 output channels the
+    weight rows in the order 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3) (a lane's accumulator registers are then 16 consecutive channels),
+    five [32][64] K chunks with the kernel's XOR swizzle applied, the biases as (hi, lo) rows (_bias_hi_lo)."""
+    n, c = weight.shape
+    assert c == 320 and n % 32 == 0
+    dt, dev = weight.dtype, weight.device
+    wf = weight.detach().float()
+    bf = None if bias is None else bias.detach().float()
+    eps, normalize = 0.0, False
+    if ln is not None:
+        gamma, beta, eps = ln
+        extra = wf @ beta.detach().float()
+        bf = extra if bf is None else bf + extra
+        wf = wf * gamma.detach().float()[None, :]
+        normalize = True
+    i = torch.arange(32, device=dev)
+    perm = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)
+    rows = (torch.arange(0, n, 32, device=dev)[:, None] + perm[None, :]).reshape(-1)
+    wp = wf[rows].to(dt).reshape(n // 32, 32, 5, 8, 8)                       # [stage][row][K chunk][slot][8]
+    r = torch.arange(32, device=dev)[:, None]
+    src_slot = torch.arange(8, device=dev)[None, :] ^ ((r >> 1) & 7)           # [32, 8]: slot s of row r holds source slot s ^ ((r >> 1) & 7)
+    sw = torch.gather(wp.permute(0, 2, 1, 3, 4), 3, src_slot[None, None, :, :, None].expand(n // 32, 5, 32, 8, 8))     # [stage][chunk][row][slot][8]
+    b8 = _bias_hi_lo(None if bf is None else bf[rows], n, dt, dev).reshape(n // 32, 32 * 8)
+    pad = torch.zeros(n // 32, 256, dtype=dt, device=dev)
+    w = torch.cat([sw.reshape(n // 32, -1), b8, pad], dim=1).contiguous()
+    assert w.shape == (n // 32, LR_STAGE_BYTES // 2)
+    return LinearRows(w, n, float(eps), normalize)
+
+
+def linear_rows_ok(channels: int, n_out: int, rows: int, dtype, rows_per_group: int = 0) -> bool:
+    """`rows_per_group` > 0: with a GroupNorm's coefficients in front (linear_rows(affine=...))."""
+    d = AaLinearRows()
+    d.rows, d.channels, d.n_out, d.ldx, d.ld_res, d.ldo, d.dtype = rows, channels, n_out, channels, n_out, n_out, _DT.get(dtype, -1)
+    if rows_per_group:
+        d.row_affine, d.rows_per_group = 16, rows_per_group          # (any non-null pointer: the check reads the geometry only)
+    return bool(_lib.get().aa_linear_rows_ok(C.byref(d)))
+
+
+def linear_rows(x: torch.Tensor, pk: LinearRows, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, affine=None) -> torch.Tensor:
+    """[LayerNorm](x) W^T + b (+ residual) for 320-channel token rows, rows in registers (pk from pack_linear_rows).
+    `affine` = (groupnorm_coef(...), rows per image group): the GroupNorm in front of this layer, applied to the rows in the registers."""
+    lib = _lib.get()
+    _check(x, residual, pk.w, out)
+    if pk.w.dtype != x.dtype or x.shape[1] != 320:
+        raise RuntimeError("linear_rows: weights were packed for another dtype / width")
+    if out is None:
+        out = torch.empty(x.shape[0], pk.n_out, dtype=x.dtype, device=x.device)
+    d = AaLinearRows()
+    d.x, d.residual, d.out, d.w = _ptr(x), _ptr(residual), _ptr(out), _ptr(pk.w)
+    d.rows, d.channels, d.n_out = x.shape[0], x.shape[1], pk.n_out
+    d.ldx, d.ld_res, d.ldo = x.stride(0), 0 if residual is None else residual.stride(0), out.stride(0)
+    d.normalize, d.ln_eps, d.dtype, d.flags = int(pk.normalize), pk.ln_eps, _DT[x.dtype], LINEAR_ROWS_DEBUG
+    if affine is not None:
+        coef, per = affine
+        if coef.dtype != torch.float32 or not coef.is_contiguous() or coef.shape[-1] != x.shape[1] or coef.shape[0] * per < x.shape[0] or coef.device != x.device:
+            raise RuntimeError("linear_rows: `affine` must be groupnorm_coef's fp32 [groups, 2, channels] covering every row")
+        d.row_affine, d.rows_per_group = _ptr(coef), per
+    _run(lib.aa_linear_rows, C.byref(d), _stream(x))
     return out
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AA_VERSION 108
+#define AA_VERSION 109
 
 enum { AA_F16 = 0, AA_BF16 = 1, AA_F32 = 2 };
 enum { AA_OK = 0, AA_E_SHAPE = -1, AA_E_DTYPE = -2, AA_E_ALIGN = -3, AA_E_WORKSPACE = -4, AA_E_HIP = -5 };
@@ -214,6 +214,11 @@ void aa_set_groupnorm_two_pass(int on);
  * if this call runs as one kernel, 0 if it runs as the statistics + normalise pair. */
 int aa_groupnorm_plan(const AaGroupNorm* d, int32_t info[4]);
 int aa_groupnorm(const AaGroupNorm* d, void* workspace, size_t workspace_bytes, void* stream);
+/* aa_groupnorm_coef (version 109): the statistics of aa_groupnorm without the normalisation pass: coef = fp32 [n_groups_img][2][c0+c1], the
+ * per-channel (scale, shift) = (gamma / sigma_g, beta - mu_g gamma / sigma_g) of every image group, for a consumer that applies them to rows it
+ * holds anyway (AaLinearRows.row_affine: GroupNorm -> proj_in of diffusers Transformer2DModel / TransformerTemporalModel, an affine-only norm;
+ * reference models/unet_3d_blocks.py:287,446,681 / :379,526,759).  d->y is not used, d->silu must be 0; workspace as for aa_groupnorm. */
+int aa_groupnorm_coef(const AaGroupNorm* d, void* workspace, size_t workspace_bytes, float* coef, void* stream);
 
 /* aa_layernorm: nn.LayerNorm(C, eps) over the last dim of [rows][C]
  * (diffusers BasicTransformerBlock.norm1/2/3). */
@@ -340,6 +345,37 @@ typedef struct AaFFFused {
 
 int aa_ff_fused_ok(const AaFFFused* d);
 int aa_ff_fused(const AaFFFused* d, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * aa_linear_rows (version 109): out = [LayerNorm](x) W^T + b (+ residual) over 320-channel token rows held in registers - the K = C projections
+ * of the 320-channel transformers (diffusers Transformer2DModel / TransformerTemporalModel.proj_in, Attention.to_q / to_out[0], the fused
+ * to_q | to_k | to_v of a spatial self-attention; reference models/unet_3d_blocks.py:287,446,681 / :379,526,759).  channels == 320, n_out a
+ * multiple of 32 (aa_linear_rows_ok); elsewhere the caller uses aa_conv_gemm.  `w` is a weight STREAM like aa_ff_fused's: n_out / 32 stage
+ * images of AA_LR_STAGE_BYTES; image s = the 32 weight rows of output channels 32 s + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3) (i = 0..31;
+ * LayerNorm's gamma folded in), all 320 K as five [32][64] chunks whose 128-byte rows hold 16-byte source slot s' ^ ((row >> 1) & 7) at slot s',
+ * then [32][8] = (hi, lo, 0 x 6) of each row's fp32 bias (+ W beta) and 512 zero bytes (ops.pack_linear_rows builds it).
+ * ---------------------------------------------------------------------------------------------- */
+#define AA_LR_STAGE_BYTES 21504
+typedef struct AaLinearRows {
+    const void* x;          /* [rows][ldx] storage dtype */
+    const void* residual;   /* [rows][ld_res] storage dtype, added to the result; may be NULL */
+    void* out;              /* [rows][ldo] */
+    const void* w;          /* (n_out / 32) x AA_LR_STAGE_BYTES */
+    int64_t rows;
+    int32_t channels, n_out;
+    int32_t ldx, ld_res, ldo;      /* row pitches in elements, multiples of 8; every operand < 2 GiB */
+    int32_t normalize;      /* 1: rows of x are normalised (ln_eps) in front of W (gamma / beta folded into the stream) */
+    float ln_eps;
+    int32_t dtype;          /* AA_F16 | AA_BF16 */
+    int32_t flags;          /* 0; debug bits: 1 = plan the launch for a 2-CU chip (tests), 2 = never split the tiles of the last round over their stages */
+    const float* row_affine;   /* NULL, or aa_groupnorm_coef's [groups][2][channels]: row r is replaced by x * scale[g] + shift[g], g = r / rows_per_group,
+                                  rounded to the storage type (what aa_groupnorm would have written), in front of `normalize` and W */
+    int32_t rows_per_group;    /* with row_affine: a multiple of 32 */
+    int32_t _pad;
+} AaLinearRows;
+
+int aa_linear_rows_ok(const AaLinearRows* d);
+int aa_linear_rows(const AaLinearRows* d, void* stream);
 
 /* aa_softmax_rows: y[r, :] = softmax(x[r, :]) for fp32 scores (VAE mid-block single-head
  * attention, head_dim 512, where scores are materialised: diffusers Attention with

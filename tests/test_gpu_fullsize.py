@@ -266,6 +266,31 @@ def test_geglu_and_ff_out_at_139264():
     close(y, (h.float() @ w2.float().t() + b2.float()).half().float() + x.float())
 
 
+def test_feedforward_and_proj_out_as_one_kernel_at_139264():
+    """aa_ff_fused at the real shape of the 64x64 level (1088 tiles = 4.25 rounds; the host's row split included): LayerNorm -> GEGLU 320 -> 2 x 1280
+    -> Linear 1280 -> 320 -> + x -> proj_out 320 -> 320 -> + outer against fp32 torch in the layer order of diffusers (no merged weights), and
+    against the two contractions it replaces."""
+    x, outer = rnd(M0, 320, seed=40), rnd(M0, 320, seed=41)
+    w1, b1 = rnd(2560, 320, scale=0.05, seed=42), rnd(2560, scale=0.2, seed=43)
+    w2, b2 = rnd(320, 1280, scale=0.03, seed=44), rnd(320, scale=0.2, seed=45)
+    wp, bp = rnd(320, 320, scale=0.05, seed=46), rnd(320, scale=0.2, seed=47)
+    gamma, beta = (1.0 + 0.3 * rnd(320, seed=48).float()).half(), rnd(320, scale=0.2, seed=49)
+    pk = ops.pack_ff_fused(w1, b1, w2, b2, wp, bp, ln=(gamma, beta, 1e-5))
+    got = ops.ff_fused(x, pk, outer)
+    m = 131072                                                  # four full rounds of 128-row tiles on 256 CUs + the rest, as layers.FeedForward splits
+    got_split = torch.empty_like(got)
+    ops.ff_fused(x[:m], pk, outer[:m], out=got_split[:m])
+    ops.ff_fused(x[m:], pk, outer[m:], out=got_split[m:])
+    assert torch.equal(got, got_split)                          # (rows are independent: any split gives the same bits)
+    for r0 in range(0, M0, 34816):                              # fp32 reference in four chunks (memory)
+        xs = x[r0:r0 + 34816].float()
+        xn = F.layer_norm(xs, (320,), gamma.float(), beta.float(), 1e-5)
+        p_ = xn @ w1.float().t() + b1.float()
+        f = (p_[:, :1280] * F.gelu(p_[:, 1280:])) @ w2.float().t() + b2.float() + xs
+        want = f @ wp.float().t() + bp.float() + outer[r0:r0 + 34816].float()
+        close(got[r0:r0 + 34816], want)
+
+
 def test_linear_640_at_34816_and_1280_at_8704():
     """Attention out-projections (+residual) of the 32x32 and 16x16 levels (the autotuned 128- / 192-row tiles)."""
     for m, c, seed in ((34816, 640, 14), (8704, 1280, 17), (2176, 1280, 20)):
