@@ -115,6 +115,12 @@ __device__ __forceinline__ void lds_read16_async(u32x4& dst, const void* lds_ptr
     const unsigned addr = (unsigned)(unsigned long long)lds_ptr;        // low 32 bits of a flat LDS pointer = LDS offset
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 }
+// Hand-issued LDS store of 16 bytes per lane (LDS operations of one wave execute in order: a later hand-issued read of the same wave sees it).
+// Unlike a plain C++ store it does not make hipcc drain the LDS-DMA queue (s_waitcnt vmcnt(0)) in front of the next read.
+__device__ __forceinline__ void lds_write16_async(void* lds_ptr, const u32x4& v) {
+    const unsigned addr = (unsigned)(unsigned long long)lds_ptr;
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
 // Wait until at most N LDS operations are outstanding; `x` becomes available to consumers here.
 template <int N>
 __device__ __forceinline__ void lds_wait(u32x4& x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N)); }

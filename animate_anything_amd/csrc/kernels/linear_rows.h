@@ -12,8 +12,8 @@
 //    for the matrix pipe: a 21st k-slice), three-stage ring, counted vmcnt, one raw barrier per stage; every stage finishes 32 output channels of the
 //    wave's 32 tokens: + residual, rounded, stored - no accumulators live across stages (176 registers, 80 KB of LDS: two workgroups per CU);
 //  * the tiles behind the last full round of the chip are split over their stages (aa_linear_rows: n_full, n_split).
-// Measured (profiles/r06_linear_rows_probe.txt, 139264 rows): 320 -> 320 61-64 us without / 73 with a residual (tile family 65-68 / 81-83), 320 -> 960
-// 142 (172); the x fetch, the stores and the multiply phase of a workgroup add up instead of overlapping (x only 27 us, + stores 39, + weights and
+// Measured (profiles/r06_linear_rows_probe.txt, 139264 rows): 320 -> 320 56-60 us without / 65 with a residual (tile family 69 / 83), 320 -> 960
+// 134 (175); the x fetch, the stores and the multiply phase of a workgroup add up instead of overlapping (x only 27 us, + stores 39, + weights and
 // MFMAs 48 on constant data), and neither three waves per SIMD, nor later stores, nor workgroups started half a life apart changed that.
 #pragma once
 #include "dev.h"
@@ -26,12 +26,17 @@ constexpr int LR_CHUNK_BYTES = 4096;              // [32 rows][64 K]: 128-byte r
 constexpr int LR_BIAS_OFF = 5 * LR_CHUNK_BYTES;   // [32 rows][8]: (bias hi, bias lo, 0 x 6), then 512 bytes of zeros
 constexpr int LR_STAGE_BYTES = LR_BIAS_OFF + 1024;
 constexpr int LR_RING = 3;
+constexpr int LR_OT_STRIDE = 80;                  // a row of a wave's [32 tokens][32 channels] output tile in LDS: 64 bytes + 16 (bank spread)
+constexpr int LR_OT_BYTES = 32 * LR_OT_STRIDE;
 constexpr int LR_X_BYTES = 20480;                 // a wave's 32 rows x 320 channels on their way to the registers: five [32][64] chunks like a weight stage's
 // the weight ring + 1 KiB that takes the pieces that fetch nothing (NW not a divisor of 20); in front of the first stage the same memory stages x
-__host__ __device__ constexpr int lr_lds_bytes(int nw = LR_NW) { return nw * LR_X_BYTES > LR_RING * LR_STAGE_BYTES + 1024 ? nw * LR_X_BYTES : LR_RING * LR_STAGE_BYTES + 1024; }
+// ... behind it the waves' output tiles (the epilogue's transposition)
+__host__ __device__ constexpr int lr_lds_bytes(int nw = LR_NW) {
+    return nw * LR_X_BYTES > LR_RING * LR_STAGE_BYTES + 1024 + nw * LR_OT_BYTES ? nw * LR_X_BYTES : LR_RING * LR_STAGE_BYTES + 1024 + nw * LR_OT_BYTES;
+}
 
 // VAR: timing-only forms for scripts/probe/linear_rows_probe.hip (bit 0: no output stores, bit 1: the weight pieces fetch nothing, bit 2: no fragment
-// reads and no MFMAs); bit 4: x straight into registers; bit 5: the split workgroups last in the grid.  (Measured and removed: a stage's stores at the top of the next stage, 192-row workgroups at three waves per SIMD, half of the first round started late - profiles/r06_linear_rows_probe.txt.)
+// reads and no MFMAs); bit 3: stores / residual loads a token per lane; bit 4: x straight into registers; bit 5: the split workgroups last in the grid.  (Measured and removed: a stage's stores at the top of the next stage, 192-row workgroups at three waves per SIMD, half of the first round started late - profiles/r06_linear_rows_probe.txt.)
 template <typename T, int C, int NW = LR_NW, int VAR = 0>
 __global__ void __launch_bounds__(64 * NW, NW / 2) linear_rows_kernel(const AaLinearRows p, const int n_full, const int n_split) {
     static_assert(C == 320, "one stage = five 32 x 64 chunks: 320 channels");
@@ -42,6 +47,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) linear_rows_kernel(const AaLi
     constexpr unsigned OOB = 0x80000000u;
     char* ring = dyn_smem();
     char* dump = ring + LR_RING * LR_STAGE_BYTES;
+    char* otile = dump + 1024 + wave_id() * LR_OT_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id();
@@ -176,8 +182,28 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) linear_rows_kernel(const AaLi
     f32x16 zero16;
 #pragma unroll
     for (int e = 0; e < 16; ++e) zero16[e] = 0.0f;
-    const unsigned ob = row_ok ? (unsigned)(row * p.ldo * 2) + (unsigned)(16 * h * 2) : OOB;
-    const unsigned rb = (row_ok && p.residual) ? (unsigned)(row * p.ld_res * 2) + (unsigned)(16 * h * 2) : OOB;
+    // Output (and residual) addressing.  The accumulators hold a token per lane (16 channels): stored from there every lane of a store instruction
+    // writes 16 bytes of ANOTHER row - 64 address cycles per instruction, the kernel's stores (and residual loads) were bound by that, not by
+    // bytes (139264 x 320: + 12 us each).  Instead a stage's [32 tokens][32 channels] go through a wave-private LDS tile, rounded, and come back
+    // four lanes to a row: lane l = (row l >> 2 (+ 16 j), 16 bytes l & 3) - a quarter of the address cycles; the residual is fetched in the
+    // same layout and added to the ROUNDED product (the order of the reference: to_out's output is a tensor of the storage type, then + residual).
+    // (VAR bit 3: the token-per-lane form.)
+    constexpr bool ROWMAJOR = !(VAR & 8);
+    const int64_t row2 = (int64_t)tile * (32 * NW) + 32 * wave + (lane >> 2);          // (+ 16 j)
+    unsigned ob, rb, ob2[2], rb2[2];
+    if constexpr (ROWMAJOR) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = row2 + 16 * j < p.rows;
+            ob2[j] = ok ? (unsigned)((row2 + 16 * j) * p.ldo * 2) + (unsigned)(16 * (lane & 3)) : OOB;
+            rb2[j] = (ok && p.residual) ? (unsigned)((row2 + 16 * j) * p.ld_res * 2) + (unsigned)(16 * (lane & 3)) : OOB;
+        }
+    } else {
+        ob = row_ok ? (unsigned)(row * p.ldo * 2) + (unsigned)(16 * h * 2) : OOB;
+        rb = (row_ok && p.residual) ? (unsigned)(row * p.ld_res * 2) + (unsigned)(16 * h * 2) : OOB;
+    }
+    char* ot_w = otile + c * LR_OT_STRIDE + 32 * h;                                      // this lane's 2 x 16 bytes of the tile (t = 0, 1: + 16 t)
+    const char* ot_r = otile + (lane >> 2) * LR_OT_STRIDE + 16 * (lane & 3);             // (+ 16 j rows)
 
     for (int q = q0; q < nq; ++q) {
         // stage top: my pieces of stage q have landed (loads return in order: at most the PPW (+ 1) pieces of stage q + 1 - the newest loads - may be
@@ -187,7 +213,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) linear_rows_kernel(const AaLi
         // this stage's residual (lane (token c, h): channels 32 q + 16 h .. + 15), in front of the younger pieces
         u32x4 res[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) res[t] = buf_load16(r_res, rb + (unsigned)((32 * q + 8 * t) * 2));          // (no residual: zeros)
+        for (int t = 0; t < 2; ++t) {
+            if constexpr (ROWMAJOR) res[t] = buf_load16(r_res, rb2[t] + (unsigned)(64 * q));                     // (no residual: zeros)
+            else res[t] = buf_load16(r_res, rb + (unsigned)((32 * q + 8 * t) * 2));
+        }
         const char* st = ring + (q % LR_RING) * LR_STAGE_BYTES;
         const char* b4[4];
 #pragma unroll
@@ -221,15 +250,43 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) linear_rows_kernel(const AaLi
             }
             sched_fence();
         });
-        // + residual, rounded, stored: register 8 t + e = channel 32 q + 16 h + 8 t + e of the lane's token (the host packs the rows in that order)
+        // rounded, (+ residual), stored: register 8 t + e = channel 32 q + 16 h + 8 t + e of the lane's token (the host packs the rows in that order)
+        if constexpr (ROWMAJOR) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            Pack8<T> r, v;
-            r.raw = res[t];
+            for (int t = 0; t < 2; ++t) {
+                Pack8<T> v;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v.e[e] = (T)(acc[8 * t + e] + (float)r.e[e]);
-            if constexpr (!(VAR & 1)) buf_store16(r_o, ob + (unsigned)((32 * q + 8 * t) * 2), v.raw);
-            else asm volatile("" ::"v"(v.raw));
+                for (int e = 0; e < 8; ++e) v.e[e] = (T)acc[8 * t + e];
+                lds_write16_async(ot_w + 16 * t, v.raw);
+            }
+            wave_sync();
+            u32x4 o[2];
+            lds_read16_async(o[0], ot_r);
+            lds_read16_async(o[1], ot_r + 16 * LR_OT_STRIDE);
+            lds_wait<1>(o[0]);
+            lds_wait<0>(o[1]);
+            wave_sync();                                                 // (emulator: every lane has read before the next stage's writes)
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                Pack8<T> r, v;
+                r.raw = res[j2]; v.raw = o[j2];
+                if (p.residual) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.e[e] = (T)((float)v.e[e] + (float)r.e[e]);
+                }
+                if constexpr (!(VAR & 1)) buf_store16(r_o, ob2[j2] + (unsigned)(64 * q), v.raw);
+                else asm volatile("" ::"v"(v.raw));
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                Pack8<T> r, v;
+                r.raw = res[t];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.e[e] = (T)(acc[8 * t + e] + (float)r.e[e]);
+                if constexpr (!(VAR & 1)) buf_store16(r_o, ob + (unsigned)((32 * q + 8 * t) * 2), v.raw);
+                else asm volatile("" ::"v"(v.raw));
+            }
         }
     }
     dma_wait<0>();                  // (the last two stages' pieces fetched nothing, but they do write LDS)

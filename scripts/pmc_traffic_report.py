@@ -15,7 +15,7 @@ root = sys.argv[1]
 def family(name):
     if "conv_gemm_dma_kernel" in name or "conv3x3_slab_kernel" in name or "conv_gemm_x_kernel" in name:
         return "contraction_kernels"                       # the LDS-DMA implicit-GEMM family (compiled, halo-slab and hand-scheduled tiles)
-    for key in ("ff_fused_kernel", "conv_gemm_kernel", "splitk_reduce", "attention_kernel", "attention_shortkv", "groupnorm_apply",
+    for key in ("ff_fused_kernel", "linear_rows_kernel", "groupnorm_coef", "conv_gemm_kernel", "splitk_reduce", "attention_kernel", "attention_shortkv", "groupnorm_apply",
                 "groupnorm_stats", "groupnorm_fused", "layernorm_kernel", "ln_finalize", "cfg_dpm_step"):
         if key == "attention_kernel" and "seq_self_attention_kernel" in name:
             return "seq_self_attention_kernel"

@@ -1,6 +1,6 @@
 // Probe (r06): where does aa::linear_rows_kernel (320-channel rows in registers) spend its time at 139264 rows?  Times the kernel's VAR forms and
 // workgroup sizes on random data (timing only - parity is tests/test_linear_rows.py through the library):
-//   VAR bit 0: no output stores   bit 1: the weight pieces fetch nothing   bit 2: no fragment reads, no MFMAs   bit 3: a stage's stores at the top of the next   bit 4: x straight into registers   bit 5: split workgroups last
+//   VAR bit 0: no output stores   bit 1: the weight pieces fetch nothing   bit 2: no fragment reads, no MFMAs   bit 3: stores / residual loads a token per lane   bit 4: x straight into registers   bit 5: split workgroups last
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffast-math -I animate_anything_amd/csrc/kernels/device -I animate_anything_amd/csrc/kernels
 //        -I animate_anything_amd/csrc -I include scripts/probe/linear_rows_probe.hip -o scripts/probe/bin/linear_rows_probe
 #include <hip/hip_runtime.h>
@@ -48,6 +48,7 @@ int main() {
                 d.x = x; d.residual = with_res ? res : nullptr; d.out = out; d.w = w; d.rows = rows; d.channels = 320; d.n_out = n_out;
                 d.ldx = 320; d.ld_res = n_out; d.ldo = n_out; d.normalize = 0; d.ln_eps = 1e-5f; d.dtype = AA_F16; d.flags = 0;
                 run<4, 0>("the kernel", d, 1);
+                run<4, 8>("stores / residual loads a token per lane (16 bytes of another row in every lane)", d, 1);
                 run<4, 32>("split workgroups last in the grid", d, 1);
                 run<4, 16>("x straight into registers (16 bytes per lane and row)", d, 1);
                 run<4, 0>("no stage split of the last round", d, 0);

@@ -282,6 +282,7 @@ inline void block_barrier() { emu::block_barrier(); }
 inline void wave_sync() { emu::wave_barrier(); }
 
 inline void lds_read16_async(u32x4& dst, const void* lds_ptr) { dst = *reinterpret_cast<const u32x4*>(lds_ptr); }
+inline void lds_write16_async(void* lds_ptr, const u32x4& v) { *reinterpret_cast<u32x4*>(lds_ptr) = v; }
 template <int N>
 inline void lds_wait(u32x4&) {}
 inline void lds_pin(u32x4&) {}
