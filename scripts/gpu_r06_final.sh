@@ -30,7 +30,7 @@ timeout 900 python bench.py --gemm-breakdown $OUT/gemm_breakdown.txt > $OUT/benc
 timeout 900 python bench.py --workload svd --gemm-breakdown $OUT/svd_gemm_breakdown.txt > $OUT/bench_svd.json 2>$OUT/bench_svd.err; echo "bench svd rc=$?" >> $OUT/summary.log
 timeout 900 python bench.py --workload rgba > $OUT/bench_rgba.json 2>$OUT/bench_rgba.err; echo "bench rgba rc=$?" >> $OUT/summary.log
 timeout 900 python bench.py --dtype bf16 --no-cpu-baseline --no-other-form > $OUT/bench_bf16.json 2>/dev/null; echo "bench bf16 rc=$?" >> $OUT/summary.log
-for knob in "AA_SEQ_ATTN=0" "AA_FF_FUSED=0" "AA_DEBUG_ABLATE=16" "AA_SEQ_ATTN=0 AA_FF_FUSED=0 AA_DEBUG_ABLATE=16"; do
+for knob in "AA_SEQ_ATTN=0" "AA_FF_FUSED=0" "AA_LINEAR_ROWS=0" "AA_GN_FOLD=0" "AA_SEQ_ATTN=0 AA_FF_FUSED=0 AA_LINEAR_ROWS=0 AA_DEBUG_ABLATE=16"; do
   tag=$(echo $knob | tr ' =' '__')
   env $knob timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-vae --no-other-form --no-roofline --tile-cache $OUT/tc_$tag.json > /dev/null 2>&1
   for rep in 1 2; do
