@@ -132,7 +132,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 2) linear_rows_kernel(const AaLi
     // would have written and this kernel read back.  A wave's 32 rows lie in one group (rows_per_group % 32 == 0): the coefficients are wave-uniform
     // (scalar loads); lane half h holds channels 32 (ks >> 1) + 8 (ks & 1) + 16 h .. + 7 of k-slice ks.
     if (p.row_affine) {
-        const int64_t grp = ((int64_t)tile * (32 * NW) + 32 * wave) / p.rows_per_group;      // (blockIdx and wave_id(): uniform)
+        const int64_t r0 = (int64_t)tile * (32 * NW) + 32 * wave;                               // (blockIdx and wave_id(): uniform)
+        const int64_t grp = (r0 < p.rows ? r0 : p.rows - 1) / p.rows_per_group;                  // (a wave behind the last row reads the last group's, never past the table)
         const float* cf = p.row_affine + grp * 2 * C;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {

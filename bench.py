@@ -35,6 +35,10 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_STEP = 44.262e12        # BASELINE.md section 2 census (2*MAC of every conv/linear/attention matmul), 16f x 512x512, CFG batch 2
 FLOP_TABLE = {(16, 64): 44.262e12, (16, 48): 23.932e12, (8, 32): 5.495e12}     # (frames, latent size) -> FLOP per step
+# The census counts the reference's arithmetic: Upsample2D = nearest x2 + a 3x3 convolution on the upsampled grid (9 taps per output pixel).  The
+# product runs it as four 2x2 convolutions on the input grid (4 taps per output pixel: ops.pack_upsample2x_weights), so 5/9 of those three
+# convolutions is never executed: 2 * 34 images * (256 * 1280^2 + 1024 * 1280^2 + 4096 * 640^2) * 9 * 5/9 at 16 f x 512 x 512.
+UPSAMPLE_FLOP_NOT_EXECUTED = 2.0 * 34 * (256 * 1280 ** 2 + 1024 * 1280 ** 2 + 4096 * 640 ** 2) * 5
 MFMA_PEAK_TFLOPS = 2500.0        # gfx950 dense bf16/fp16 (MI355X_MICROARCH.md)
 
 
@@ -600,7 +604,7 @@ def bench(a, selftest=False):
         other = {"cfg_shared_prefix": not a.cfg_shared_prefix, "value": round(world * a.steps / dto, 4), "ms_per_step": round(dto / a.steps * 1e3, 3),
                  "note": "same step with the text-independent UNet prefix (conv_in, transformer_in, first resnet / temporal conv / spatial "
                          "self-attention) computed once per guidance pair instead of twice: the same arithmetic per element on other tiles (other "
-                         "summation orders), 42.621 instead of 44.262 TFLOP executed; the measured difference of the latents after two steps "
+                         "summation orders), 1.641 TFLOP less executed; the measured difference of the latents after two steps "
                          "is max_abs_latent_difference_after_2_steps (fp16 rounding noise amplified by guidance 9 on random weights; "
                          "tests/test_gpu_fullsize.py bounds it by the measured noise floor of the strict form and checks both forms against the oracle)"}
         # cross-check of the two forms where rounding differences have not been amplified yet by the (random-weight, guidance 9)
@@ -614,7 +618,9 @@ def bench(a, selftest=False):
         other["latent_abs_max_after_2_steps"] = two[0].abs().max().item()
         pipe.cfg_shared_prefix = bool(a.cfg_shared_prefix)
     flop_full = FLOP_TABLE.get((a.frames, lat), FLOP_PER_STEP * (a.frames + 1) / 17 * (lat / 64) ** 2)
-    flop_step = flop_full - (1.641e12 * flop_full / FLOP_PER_STEP if a.cfg_shared_prefix else 0.0)
+    # `flop_per_step_reference` = the census of the reference's arithmetic; `flop_per_step_executed` (what the rates below are computed from) leaves
+    # out what the product does not run: the 5 of 9 upsampler taps, and the text-independent prefix of one guidance half in the shared-prefix form
+    flop_step = flop_full - UPSAMPLE_FLOP_NOT_EXECUTED * flop_full / FLOP_PER_STEP - (1.641e12 * flop_full / FLOP_PER_STEP if a.cfg_shared_prefix else 0.0)
     ms_step = dt / a.steps * 1e3
     value = world * a.steps / dt
     if world > 1 and ops.AUTOTUNE_EVENTS and rank == 0:
@@ -633,7 +639,7 @@ def bench(a, selftest=False):
                    "collective": "none in the data path; one all_gather_into_tensor of the final latents (RCCL)" if world > 1 else "none"},
         "per_rank_ms_per_step": per_rank_ms,
         "tflops_per_gpu": round(flop_step * (a.steps / dt) / 1e12, 2),
-        "flop_per_step_executed": flop_step, "cfg_shared_prefix": bool(a.cfg_shared_prefix), "other_form": other,
+        "flop_per_step_executed": flop_step, "flop_per_step_reference": flop_full, "cfg_shared_prefix": bool(a.cfg_shared_prefix), "other_form": other,
     }
 
     if rank == 0 and not a.no_roofline:
