@@ -291,6 +291,50 @@ def test_feedforward_and_proj_out_as_one_kernel_at_139264():
         close(got[r0:r0 + 34816], want)
 
 
+def test_k_equals_c_projections_with_the_rows_in_registers_at_139264():
+    """aa_linear_rows at the real shapes of the 64x64 level (1088 tiles = 2.125 rounds: the launch with its last round split over the stages)
+    against fp32 torch: norm2 -> to_q, to_out + residual, norm1 -> Q|K|V (960 outputs), and proj_in behind the per-image GroupNorm of
+    Transformer2DModel (34 images x 4096 tokens) / the per-clip one of TransformerTemporalModel (2 clips x 17 x 4096) - and the same bits
+    without the stage split."""
+    x = rnd(M0, 320, seed=60)
+    gamma, beta = (1.0 + 0.3 * rnd(320, seed=61).float()).half(), rnd(320, scale=0.2, seed=62)
+
+    def chunks(fn):                                             # fp32 reference in four chunks (memory)
+        for r0 in range(0, M0, 34816):
+            fn(slice(r0, r0 + 34816))
+
+    for n_out, ln, with_res, seed in ((320, True, False, 63), (320, False, True, 66), (960, True, False, 69)):
+        w, b = rnd(n_out, 320, scale=0.05, seed=seed), (None if n_out == 960 else rnd(n_out, scale=0.2, seed=seed + 1))
+        res = rnd(M0, n_out, seed=seed + 2) if with_res else None
+        pk = ops.pack_linear_rows(w, b, ln=(gamma, beta, 1e-5) if ln else None)
+        got = ops.linear_rows(x, pk, res)
+        ops.LINEAR_ROWS_DEBUG = 2
+        try:
+            assert torch.equal(got, ops.linear_rows(x, pk, res))
+        finally:
+            ops.LINEAR_ROWS_DEBUG = 0
+
+        def check(sl):
+            xs = x[sl].float()
+            xn = F.layer_norm(xs, (320,), gamma.float(), beta.float(), 1e-5) if ln else xs
+            want = xn @ w.float().t() + (0.0 if b is None else b.float()) + (0.0 if res is None else res[sl].float())
+            close(got[sl], want)
+        chunks(check)
+    # GroupNorm -> proj_in: statistics per image (spatial transformer) and per clip (temporal transformer), eps 1e-6 as in diffusers
+    w, b = rnd(320, 320, scale=0.05, seed=72), rnd(320, scale=0.2, seed=73)
+    pk = ops.pack_linear_rows(w, b)
+    xg = (x.float() * (1.0 + rnd(1, 320, seed=74).float().abs()) + 2.0 * rnd(1, 320, seed=75).float()).half()      # (channels of different scale and mean)
+    for groups_img, per in ((N_IMG, HW), (B, T * HW)):
+        coef = ops.groupnorm_coef(xg, gamma, beta, groups_img, per, 32, 1e-6)
+        got = ops.linear_rows(xg, pk, affine=(coef, per))
+        two = ops.linear_rows(ops.groupnorm(xg, gamma, beta, groups_img, per, 32, 1e-6), pk)
+        close(got, two, tol=2e-3)
+        for gi in range(0, groups_img, max(1, groups_img // 4)):                       # fp32 reference on a few image groups
+            xi = xg[gi * per:(gi + 1) * per].float().t()[None]                         # [1, C, tokens]
+            xn = F.group_norm(xi, 32, gamma.float(), beta.float(), 1e-6)[0].t()
+            close(got[gi * per:(gi + 1) * per], xn @ w.float().t() + b.float())
+
+
 def test_linear_640_at_34816_and_1280_at_8704():
     """Attention out-projections (+residual) of the 32x32 and 16x16 levels (the autotuned 128- / 192-row tiles)."""
     for m, c, seed in ((34816, 640, 14), (8704, 1280, 17), (2176, 1280, 20)):
