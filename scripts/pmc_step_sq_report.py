@@ -15,8 +15,8 @@ root = sys.argv[1]
 def family(name):
     if "conv_gemm_dma_kernel" in name or "conv3x3_slab_kernel" in name or "conv_gemm_x_kernel" in name:
         return "contraction_kernels"
-    for key in ("conv_gemm_kernel", "splitk_reduce", "attention_kernel", "attention_shortkv", "groupnorm_apply", "groupnorm_stats", "groupnorm_fused",
-                "layernorm_kernel", "ln_finalize"):
+    for key in ("ff_fused_kernel", "linear_rows_kernel", "seq_self_attention_kernel", "conv_gemm_kernel", "splitk_reduce", "attention_kernel", "attention_shortkv",
+                "groupnorm_apply", "groupnorm_stats", "groupnorm_fused", "groupnorm_coef", "layernorm_kernel", "ln_finalize"):
         if key in name:
             return key
     return None
